@@ -1,0 +1,162 @@
+/* mdd.h -- C ABI of libmdd_hip.so: MI355X (gfx950) MinHash-LSH near-dedup hot path.
+ *
+ * Drop-in boundary for the document near-deduplication stage of MAP-NEO's Matrix pipeline.
+ * The reference has no FFI of its own (the stage is Python scripts whose arithmetic lives in
+ * datasketch / hashlib / numpy); each entry point below names the reference
+ * function(s) it replaces.  Reference paths are relative to /root/reference:
+ *   EN   = Matrix/english_data_clean_pipeline/dedup/Minhash_Lsh_Deduplication/minhashLsh.py
+ *   ZH-1 = Matrix/chinese_data_clean_pipeline/deduplication/minhash_lsh/generate_minhash.py
+ *   ZH-2 = Matrix/chinese_data_clean_pipeline/deduplication/minhash_lsh/generate_dup_pairs.py
+ *   ZH-3 = Matrix/chinese_data_clean_pipeline/deduplication/minhash_lsh/generate_connected_components.py
+ *   ZH-4 = Matrix/chinese_data_clean_pipeline/deduplication/minhash_lsh/generate_dup_line_id_for_each_file.py
+ *
+ * Conventions
+ *  - every function returns 0 (MDD_OK) or a negative error code; the message of the last
+ *    error on the calling thread is returned by mdd_last_error().  No C++ exception and no
+ *    torch type crosses this boundary: plain pointers and sizes only.
+ *  - unless a parameter says "host", every pointer is a DEVICE pointer on the context's GPU.
+ *    The caller owns every buffer (inputs, outputs AND workspaces); the compute entry points
+ *    allocate nothing, keep no pointer after they return, and enqueue their kernels on the
+ *    context's stream (asynchronous; call mdd_ctx_sync or synchronise the stream yourself).
+ *  - a context is bound to one (device, stream) pair and is not thread-safe: one per rank.
+ *  - there is no CPU fallback: on a machine without a usable GPU mdd_ctx_create fails.
+ */
+#ifndef MDD_H
+#define MDD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDD_OK 0
+#define MDD_ERR_INVALID (-1)     /* bad argument (null pointer, size out of range, misalignment) */
+#define MDD_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define MDD_ERR_UNSUPPORTED (-3) /* parameter combination this build does not implement */
+
+#define MDD_UNIT_CHAR 0 /* shingle unit = Unicode code point (EN:61, ZH-1:27: nltk.ngrams over a str) */
+#define MDD_UNIT_WORD 1 /* shingle unit = space-separated token (BASELINE.json config 1; extension) */
+
+#define MDD_MAX_PERM 256
+#define MDD_MAX_BANDS 64
+#define MDD_NO_EDGE 0xFFFFFFFFu
+
+typedef struct mdd_ctx mdd_ctx;
+
+/* Library identification / error reporting. */
+int mdd_version(void);
+const char* mdd_last_error(void);
+
+/* Context = (device, stream).  `hip_stream` may be NULL (the library creates and owns a
+ * stream) or an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out);
+int mdd_ctx_destroy(mdd_ctx* ctx);
+int mdd_ctx_sync(mdd_ctx* ctx);
+
+/* Permutation table.  Replaces datasketch MinHash.__init__/_init_permutations, which the
+ * reference re-runs for every document through `MinHash(num_perm=128)` (EN:62, ZH-1:28):
+ * numpy legacy RandomState(seed); for i<K: a_i = randint(1, 2^61-1), b_i = randint(0, 2^61-1)
+ * (interleaved draws, dtype uint64).  HOST pointers, K <= MDD_MAX_PERM.  Needs no GPU. */
+int mdd_make_perms(uint32_t seed, int K, uint64_t* a_host, uint64_t* b_host);
+
+/* Signatures.  Replaces generate_minhash_value (EN:56-64) and the first half of
+ * generate_hash_values (ZH-1:23-29) for a whole batch of already-normalised documents:
+ * shingle (code-point or token windows of `width`, no padding) -> utf-8 bytes -> SHA-1 ->
+ * hv = little-endian u32 of digest[0:4] -> for i<K:
+ *   sig[i] = min(sig[i], ((a_i*hv + b_i) mod 2^64) mod (2^61-1) & 0xFFFFFFFF), init 0xFFFFFFFF.
+ *  text       packed utf-8 of all documents, 4-byte aligned; the allocation must extend to
+ *             a multiple of 4 bytes past text_bytes (padding content is ignored)
+ *  offsets    n_docs+1 ascending byte offsets into text (document d = [offsets[d], offsets[d+1]))
+ *             each document must be shorter than 4 GiB
+ *  a, b       device copies of the permutation table (K entries each)
+ *  sig_out    n_docs*K u32, row-major (the reference keeps uint64 hashvalues < 2^32)
+ * 1 <= K <= 256; char: 1 <= width <= 128; word: 1 <= width <= 128. */
+int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
+                   uint64_t n_docs, int unit, int width, int K, const uint64_t* a, const uint64_t* b,
+                   uint32_t* sig_out);
+
+/* Stage probe for parity tests: the shingle hashes (a2+a3: datasketch sha1_hash32 of every
+ * shingle, in shingle order) of ONE document [doc_begin, doc_end) of `text`.  Writes at most
+ * `cap` hashes; *n_out (device u64) receives the number of shingles of the document. */
+int mdd_shingle_hashes(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, uint64_t doc_begin,
+                       uint64_t doc_end, int unit, int width, uint32_t* out, uint64_t cap, uint64_t* n_out);
+
+/* Band records.  Replaces generate_bands (EN:66-71) / tail of generate_hash_values
+ * (ZH-1:30-33): record i = doc*bands + band carries the r-tuple sig[doc][band*rows ..+rows).
+ * The reference serialises the tuple as 8*rows big-endian bytes; here the tuple stays in
+ * `sig` and the record gets
+ *   key[i]  = 64-bit surrogate hash of (band, tuple), never 0 (used for hashing only --
+ *             bucket identity is decided on the exact tuple in mdd_bucket_edges)
+ *   meta[i] = (band << 56) | (doc_base + doc)      (global document index, < 2^32)
+ * bands*rows <= K, bands <= MDD_MAX_BANDS.  `key_bits` (1..64) truncates the surrogate
+ * (tests use a few bits to force surrogate collisions); pass 64. */
+int mdd_band_keys(mdd_ctx* ctx, const uint32_t* sig, uint64_t n_docs, int K, int bands, int rows,
+                  uint64_t doc_base, int key_bits, uint64_t* key, uint64_t* meta);
+
+/* Same surrogate for records in PACKED layout (after the multi-GPU exchange): tuple of record
+ * i = tuples[i*rows ..+rows), band = meta[i] >> 56. */
+int mdd_packed_keys(mdd_ctx* ctx, const uint32_t* tuples, const uint64_t* meta, uint64_t n_rec, int rows,
+                    int key_bits, uint64_t* key);
+
+/* Multi-GPU routing (new design; no counterpart in the reference, which
+ * leaves the shuffle to Spark EN:136 / the filesystem ZH-1:58-61): destination rank of a
+ * record = (key >> 32) mod world.  mdd_route_count histograms records per rank into
+ * counts[world] (device u64, zeroed by the call); mdd_route_pack writes the records in
+ * PACKED layout grouped by rank at send_offsets[rank] (device u64[world], exclusive prefix of
+ * counts, advanced by the call -- pass a scratch copy). */
+int mdd_route_count(mdd_ctx* ctx, const uint64_t* key, uint64_t n_rec, int world, uint64_t* counts);
+int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows, const uint64_t* key,
+                   const uint64_t* meta, uint64_t n_rec, int world, uint64_t* send_cursor,
+                   uint32_t* tuples_out, uint64_t* meta_out);
+
+/* Bucketing + edges.  Replaces groupBy((band,key)) + generate_edges (EN:136, EN:73-80) and
+ * the per-band dict of ZH-2:19-40.  Bucket identity = exact equality of (band, r-tuple).
+ * Records are described by (key, meta) plus tuple addressing:
+ *   tuple(i) = tuple_base + (i / rec_per_doc)*doc_stride + (i % rec_per_doc)*band_stride
+ *   SIG layout:    tuple_base = sig, rec_per_doc = bands, doc_stride = K, band_stride = rows
+ *   PACKED layout: tuple_base = tuples, rec_per_doc = 1, doc_stride = rows, band_stride = 0
+ * Workspace (caller-allocated): tab_key u64[tab_size], tab_rep u32[tab_size]; tab_size a
+ * power of two >= 2*n_rec.  The call clears it.
+ * Output: for every record that is not the representative (lowest record index) of its
+ * bucket one edge (doc, doc_of_representative), appended to edge_u/edge_v (u32 global doc
+ * indices; order of edges unspecified, set deterministic).  *n_edges (device u64) counts
+ * them; at most edge_cap are written (n_rec always suffices).
+ * Records whose surrogate key equals another bucket's but whose tuple differs (surrogate
+ * collisions) are NOT linked here: their record indices are appended to coll_idx (u64,
+ * capacity coll_cap) and counted in *n_coll (device u64); the caller resolves them exactly
+ * (map_neo_amd.dedup does, on the host).  rec_bucket (optional, may be NULL): u64[n_rec],
+ * record index of the representative of the record's surrogate slot (bucket id for tests). */
+int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, uint64_t n_rec,
+                     const uint32_t* tuple_base, uint64_t rec_per_doc, uint64_t doc_stride,
+                     uint64_t band_stride, int rows, uint64_t* tab_key, uint32_t* tab_rep,
+                     uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap,
+                     uint64_t* n_edges, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll,
+                     uint64_t* rec_bucket);
+
+/* Connected components.  Replaces the large-star/small-star loop (EN:82-115, EN:138-144)
+ * and networkit ConnectedComponents (ZH-3:11-27): union-find over n_docs global indices;
+ * labels[d] = smallest document index of d's component (what EN:145 keeps).
+ * mdd_components_init sets labels[d] = d; mdd_components_union may be called repeatedly
+ * (e.g. once per gathered edge shard); mdd_components_finish flattens. */
+int mdd_components_init(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs);
+int mdd_components_union(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs, const uint32_t* edge_u,
+                         const uint32_t* edge_v, uint64_t n_edges);
+int mdd_components_finish(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs);
+
+/* Removal rule.  Replaces EN:145-149 (every non-minimum member of a component is removed)
+ * and ZH-4:17-22 (members [1:] of each component): removed[d] = labels[first+d] != first+d for
+ * the n documents starting at global index `first`; *n_removed (device u64) = their count. */
+int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint64_t n, uint8_t* removed,
+                     uint64_t* n_removed);
+
+/* Measurement helper: runs `iters` iterations of a dependency-free
+ * v_xor/v_add/v_lshr mix on every CU and reports the measured int32 VALU lane-op rate in
+ * *tops_host (HOST double, 1e12 lane-ops/s).  Synchronous. */
+int mdd_valu_calibrate(mdd_ctx* ctx, int iters, double* tops_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDD_H */

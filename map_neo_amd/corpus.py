@@ -1,0 +1,174 @@
+"""Seeded synthetic corpora -- bench/test input, not part of the hot path.
+
+Counter-based: every token of every document is a pure function of (seed, doc, position),
+computed with wrapping int64 arithmetic in torch, so the same corpus is produced on CPU and
+on the GPU, in any chunking.  Documents are generated already normalised (EN:31-40 is the
+identity on them): lowercase a-z pseudo-words joined by single spaces (EN), or runs of CJK
+code points (ZH, 3 utf-8 bytes each, no separators).
+
+Near-duplicates: a fraction `dup_frac` of documents copies the token stream of an earlier
+"source" document and substitutes each token with probability `edit_rate` (clusters of
+several near-copies form around popular sources).  A fraction `short_frac` of documents is
+shorter than the shingle width (they all share the all-0xFFFFFFFF signature).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+VOCAB_EN = 50_000
+VOCAB_ZH = 6_000
+_M64 = (1 << 64) - 1
+
+
+def _i64(x: int) -> int:
+    x &= _M64
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+_C1 = _i64(0xBF58476D1CE4E5B9)
+_C2 = _i64(0x94D049BB133111EB)
+_GOLD = _i64(0x9E3779B97F4A7C15)
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def mix64(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (wrapping)."""
+    x = (x ^ _lsr(x, 30)) * _C1
+    x = (x ^ _lsr(x, 27)) * _C2
+    return x ^ _lsr(x, 31)
+
+
+def _h(seed: int, a: torch.Tensor, b) -> torch.Tensor:
+    return mix64(mix64(a * _GOLD + _i64(seed)) ^ (b * _C2 + 0x632BE5AB))
+
+
+def _zipf_thresholds(vocab: int) -> np.ndarray:
+    w = 1.0 / np.arange(1, vocab + 1, dtype=np.float64)
+    cdf = np.cumsum(w) / w.sum()
+    thr = np.minimum(np.floor(cdf * 2.0 ** 32), 2.0 ** 32 - 1).astype(np.int64)
+    thr[-1] = (1 << 32) - 1
+    return thr
+
+
+class CorpusSpec:
+    def __init__(self, n_docs: int, mean_bytes: int = 2048, seed: int = 20240519, lang: str = "en",
+                 dup_frac: float = 0.15, edit_rate: float = 0.02, short_frac: float = 0.001,
+                 sigma: float = 0.6):
+        assert lang in ("en", "zh", "mixed")
+        self.n_docs, self.mean_bytes, self.seed, self.lang = n_docs, mean_bytes, seed, lang
+        self.dup_frac, self.edit_rate, self.short_frac, self.sigma = dup_frac, edit_rate, short_frac, sigma
+        rng = np.random.Generator(np.random.PCG64(seed))
+        n = n_docs
+        # language per document
+        if lang == "mixed":
+            self.is_zh = rng.random(n) < 0.5
+        else:
+            self.is_zh = np.full(n, lang == "zh")
+        # bytes per token: EN words 2..10 chars + space ~ 7 ; ZH 3
+        tok_bytes = np.where(self.is_zh, 3.0, 7.0)
+        mu = math.log(mean_bytes) - 0.5 * sigma * sigma
+        nbytes = rng.lognormal(mu, sigma, n)
+        ntok = np.maximum(1, np.round(nbytes / tok_bytes)).astype(np.int64)
+        short = rng.random(n) < short_frac
+        ntok[short] = rng.integers(0, 3, short.sum())           # 0..2 tokens: below 13 code points
+        # duplicate structure: source document of every document
+        src = np.arange(n, dtype=np.int64)
+        is_dup = rng.random(n) < dup_frac
+        is_dup[0] = False
+        idx = np.nonzero(is_dup)[0]
+        if idx.size:
+            # pick an earlier document; squaring the uniform favours few popular sources -> clusters
+            u = rng.random(idx.size) ** 2
+            s = np.minimum((u * idx).astype(np.int64), idx - 1)
+            s = src[s]                      # sources were assigned in order, so src[s] is final for s < idx
+            # ensure the chain is flattened (source of a dup must be an original)
+            for _ in range(4):
+                s = np.where(is_dup[s], src[s], s)
+            src[idx] = s
+            is_dup[idx] = src[idx] != idx
+        ntok = ntok[src]                    # near-copies keep the token count of their source
+        self.is_zh = self.is_zh[src]
+        self.src, self.is_dup, self.ntok = src, is_dup, ntok
+        self.thr_en = _zipf_thresholds(VOCAB_EN)
+        self.thr_zh = _zipf_thresholds(VOCAB_ZH)
+
+
+def _tokens(spec: CorpusSpec, d0: int, d1: int, device) -> Tuple[torch.Tensor, ...]:
+    """token ids / doc / pos for documents [d0, d1)."""
+    ntok = torch.from_numpy(spec.ntok[d0:d1]).to(device)
+    nd = d1 - d0
+    doc_local = torch.repeat_interleave(torch.arange(nd, device=device), ntok)
+    first = torch.cumsum(ntok, 0) - ntok
+    pos = torch.arange(doc_local.numel(), device=device) - first[doc_local]
+    doc = doc_local + d0
+    src = torch.from_numpy(spec.src[d0:d1]).to(device)[doc_local]
+    is_dup = torch.from_numpy(spec.is_dup[d0:d1]).to(device)[doc_local]
+    is_zh = torch.from_numpy(spec.is_zh[d0:d1]).to(device)[doc_local]
+    u_src = _lsr(_h(spec.seed, src, pos), 32)
+    u_own = _lsr(_h(spec.seed + 1, doc, pos), 32)
+    edit = is_dup & (_lsr(_h(spec.seed + 2, doc, pos), 32) < int(spec.edit_rate * 2 ** 32))
+    u = torch.where(edit, u_own, u_src)
+    thr_en = torch.from_numpy(spec.thr_en).to(device)
+    thr_zh = torch.from_numpy(spec.thr_zh).to(device)
+    tok = torch.where(is_zh, torch.searchsorted(thr_zh, u).clamp_(max=VOCAB_ZH - 1),
+                      torch.searchsorted(thr_en, u).clamp_(max=VOCAB_EN - 1))
+    return tok, doc_local, pos, is_zh, ntok
+
+
+def generate(spec: CorpusSpec, d0: int = 0, d1: Optional[int] = None, device="cpu"):
+    """Packed utf-8 text (uint8, padded with >= 4 zero bytes to a multiple of 4) and int64
+    offsets[n+1] for documents [d0, d1) of the corpus."""
+    d1 = spec.n_docs if d1 is None else d1
+    device = torch.device(device)
+    tok, doc_local, pos, is_zh, ntok = _tokens(spec, d0, d1, device)
+    nd = d1 - d0
+    # token byte length (without separator): EN 2..10 from the word id, ZH 3
+    wl = 2 + (_lsr(mix64(tok * _GOLD + 12345), 33) % 9)
+    tlen = torch.where(is_zh, torch.full_like(wl, 3), wl)
+    last = pos == (ntok[doc_local] - 1)
+    sep = (~is_zh) & (~last)                                 # EN tokens are followed by one space except the last
+    tbytes = tlen + sep.to(torch.int64)
+    tstart = torch.cumsum(tbytes, 0) - tbytes
+    total = int(tbytes.sum().item()) if tbytes.numel() else 0
+    doc_bytes = torch.zeros(nd, dtype=torch.int64, device=device)
+    doc_bytes.index_add_(0, doc_local, tbytes)
+    offsets = torch.zeros(nd + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(doc_bytes, 0)
+    cap = ((total + 3) // 4) * 4 + 4
+    text = torch.zeros(cap, dtype=torch.uint8, device=device)
+    if total:
+        tid = torch.repeat_interleave(torch.arange(tok.numel(), device=device), tbytes)
+        k = torch.arange(total, device=device) - tstart[tid]
+        t = tok[tid]
+        zh = is_zh[tid]
+        en_char = 97 + (_lsr(mix64(t * 1315423911 + k * _C1 + 77), 35) % 26)
+        en_byte = torch.where(k < tlen[tid], en_char, torch.full_like(en_char, 32))
+        cp = 0x4E00 + t                                      # 3-byte utf-8: 1110xxxx 10xxxxxx 10xxxxxx
+        zh_byte = torch.where(k == 0, 0xE0 | (cp >> 12), torch.where(k == 1, 0x80 | ((cp >> 6) & 0x3F), 0x80 | (cp & 0x3F)))
+        text[:total] = torch.where(zh, zh_byte, en_byte).to(torch.uint8)
+    return text, offsets
+
+
+def generate_chunked(spec: CorpusSpec, device, docs_per_chunk: int = 32768):
+    """Whole corpus on `device`, generated chunk-wise to bound temporaries."""
+    texts, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=device)], 0
+    for d0 in range(0, spec.n_docs, docs_per_chunk):
+        d1 = min(spec.n_docs, d0 + docs_per_chunk)
+        t, o = generate(spec, d0, d1, device)
+        nb = int(o[-1].item())
+        texts.append(t[:nb])
+        offs.append(o[1:] + base)
+        base += nb
+    total = base
+    cap = ((total + 3) // 4) * 4 + 4
+    text = torch.zeros(cap, dtype=torch.uint8, device=device)
+    if texts:
+        torch.cat(texts, out=text[:total])
+    return text, torch.cat(offs)

@@ -1,0 +1,1034 @@
+// libmdd_hip.so -- MinHash-LSH near-dedup hot path for MI355X (gfx950 / CDNA4).
+// C ABI: include/mdd.h.  Hand-written HIP; no CPU fallback, no CUDA dual path.
+//
+// Kernel map (reference function each replaces: see include/mdd.h)
+//   sig_kernel<KPL,DUMP>   shingle -> SHA-1 -> K-way permute-min.  VALU-bound.
+//       one WAVE per document; lanes own shingles during the SHA-1 phase (one shingle per
+//       lane), then lanes own PERMUTATIONS (lane l owns perms l, l+64, ...) while the 64
+//       shingle hashes of the round are broadcast out of LDS (ds_read_b128, same address in
+//       every lane), so the K running minima never leave their VGPRs and no cross-lane
+//       reduction is needed.
+//   band_keys_kernel / packed_keys_kernel / route_* / bucket_* / uf_* / removed_kernel:
+//       HBM-bound byte/integer work, one thread per record or document.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mdd.h"
+
+// ------------------------------------------------------------------------------------------
+// host-side plumbing
+// ------------------------------------------------------------------------------------------
+struct mdd_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    int cus;
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(MDD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+#define REQUIRE(cond, ...)                                   \
+    do {                                                     \
+        if (!(cond)) return fail(MDD_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+constexpr uint64_t P61 = (1ULL << 61) - 1;
+
+// ------------------------------------------------------------------------------------------
+// numpy legacy RandomState(seed).randint stream (host) -- datasketch _init_permutations
+// ------------------------------------------------------------------------------------------
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx;
+    explicit Mt19937(uint32_t seed) {
+        mt[0] = seed;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    uint32_t next32() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; k++) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint64_t next64() {
+        uint64_t hi = next32();
+        uint64_t lo = next32();
+        return (hi << 32) | lo;
+    }
+    // randint(low, high, dtype=uint64) with high-low-1 > 2^32: masked rejection sampling
+    uint64_t randint(uint64_t low, uint64_t high_excl) {
+        uint64_t rng = high_excl - low - 1, mask = rng;
+        for (int s = 1; s < 64; s <<= 1) mask |= mask >> s;
+        uint64_t v;
+        do v = next64() & mask; while (v > rng);
+        return low + v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// device: SHA-1
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rol(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+
+// 80 rounds over a 16-word circular schedule; fully unrolled so that message words the
+// caller set to literal 0 fold away (a 13-byte ASCII shingle has 11 zero words of 16).
+__device__ __forceinline__ void sha1_compress(uint32_t (&st)[5], uint32_t (&w)[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4];
+#pragma unroll
+    for (int t = 0; t < 80; t++) {
+        if (t >= 16) {
+            uint32_t x = w[(t - 3) & 15] ^ w[(t - 8) & 15] ^ w[(t - 14) & 15] ^ w[t & 15];
+            w[t & 15] = rol(x, 1);
+        }
+        uint32_t f, k;
+        if (t < 20) {
+            f = d ^ (b & (c ^ d));
+            k = 0x5A827999u;
+        } else if (t < 40) {
+            f = b ^ c ^ d;
+            k = 0x6ED9EBA1u;
+        } else if (t < 60) {
+            f = (b & c) | (d & (b ^ c));
+            k = 0x8F1BBCDCu;
+        } else {
+            f = b ^ c ^ d;
+            k = 0xCA62C1D6u;
+        }
+        uint32_t tmp = rol(a, 5) + f + e + k + w[t & 15];
+        e = d;
+        d = c;
+        c = rol(b, 30);
+        b = a;
+        a = tmp;
+    }
+    st[0] += a;
+    st[1] += b;
+    st[2] += c;
+    st[3] += d;
+    st[4] += e;
+}
+
+struct TextView {
+    const uint32_t* t32;  // 4-byte aligned base of the packed text
+    uint64_t last;        // index of the last dword that may be loaded
+};
+
+__device__ __forceinline__ uint32_t ld_dword(const TextView& tv, uint64_t idx) {
+    return tv.t32[idx < tv.last ? idx : tv.last];
+}
+
+// Big-endian message word covering message bytes [pos, pos+4) of a message of L bytes,
+// rem = L - pos: data bytes, then the 0x80 pad, then zeros.  (lo,hi) are the two aligned
+// little-endian dwords that contain the 4 bytes at byte shift sh.
+__device__ __forceinline__ uint32_t msg_word(uint32_t lo, uint32_t hi, uint32_t sh, int rem) {
+    uint32_t le = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    uint32_t be = __builtin_bswap32(le);
+    if (rem >= 4) return be;
+    if (rem < 0) return 0u;
+    uint32_t keep = ~(0xFFFFFFFFu >> (8 * rem));
+    if (rem == 0) keep = 0u;
+    return (be & keep) | (0x80000000u >> (8 * rem));
+}
+
+// datasketch sha1_hash32 of the L-byte shingle at absolute byte offset s, single block.
+// NW = number of leading message words that can be non-zero; requires L <= 4*NW - 1.
+template <int NW>
+__device__ __forceinline__ uint32_t hash_single(const TextView& tv, uint64_t s, uint32_t L) {
+    uint64_t base = s >> 2;
+    uint32_t sh = (uint32_t)s & 3u;
+    uint32_t dw[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; k++) dw[k] = ld_dword(tv, base + k);
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = msg_word(dw[k], dw[k + 1], sh, (int)L - 4 * k);
+#pragma unroll
+    for (int k = NW; k < 15; k++) w[k] = 0u;
+    w[15] = L * 8u;
+    uint32_t st[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+    sha1_compress(st, w);
+    return __builtin_bswap32(st[0]);  // '<I' of digest[0:4]
+}
+
+// any length (multi-block); lanes may run different block counts
+__device__ __noinline__ uint32_t hash_multi(const TextView& tv, uint64_t s, uint32_t L) {
+    uint64_t base = s >> 2;
+    uint32_t sh = (uint32_t)s & 3u;
+    uint32_t nblk = (L + 8u) / 64u + 1u;
+    uint32_t st[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+    for (uint32_t bi = 0; bi < nblk; bi++) {
+        uint32_t w[16];
+        uint32_t lo = ld_dword(tv, base + 16ull * bi);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            uint32_t hi = ld_dword(tv, base + 16ull * bi + k + 1);
+            w[k] = msg_word(lo, hi, sh, (int)L - (int)(64u * bi) - 4 * k);
+            lo = hi;
+        }
+        if (bi == nblk - 1) w[15] = L * 8u;  // L < 2^29 is enforced on the host
+        sha1_compress(st, w);
+    }
+    return __builtin_bswap32(st[0]);
+}
+
+// wave-uniform dispatch on the longest shingle of the round
+__device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint64_t s, uint32_t L, uint32_t Lmax) {
+    if (Lmax <= 15u) return hash_single<4>(tv, s, L);
+    if (Lmax <= 39u) return hash_single<10>(tv, s, L);
+    if (Lmax <= 55u) return hash_single<14>(tv, s, L);
+    return hash_multi(tv, s, L);
+}
+
+// ------------------------------------------------------------------------------------------
+// device: wave helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t below(uint64_t m) {  // set bits of m in lanes below this one
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t y = (uint32_t)__shfl_xor((int)x, o, 64);
+        x = x > y ? x : y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ void wave_sync() {  // order this wave's LDS traffic (DS ops issue in order; this pins the compiler)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int WAVES = 4;         // waves (= documents in flight) per workgroup
+constexpr int RING = 512;        // code-point / token boundary ring per wave (entries)
+constexpr uint32_t FAST_GUARD = 8u;
+
+struct __attribute__((aligned(16))) WaveLds {
+    uint32_t hbuf[64];     // shingle hashes of the current round
+    uint32_t ringS[RING];  // unit start offsets (doc-relative)
+    uint32_t ringE[RING];  // unit end offsets (word unit only)
+};
+
+// ------------------------------------------------------------------------------------------
+// sig_kernel
+// ------------------------------------------------------------------------------------------
+struct SigArgs {
+    const uint8_t* text;
+    uint64_t text_bytes;
+    const uint64_t* offsets;
+    uint64_t n_docs;
+    int unit;
+    int width;
+    int K;
+    const uint64_t* a;
+    const uint64_t* b;
+    uint32_t* sig;
+    // DUMP mode (mdd_shingle_hashes): one document, hashes written in shingle order
+    uint64_t doc_begin, doc_end;
+    uint32_t* dump;
+    uint64_t dump_cap;
+    uint64_t* dump_n;
+};
+
+template <int KPL, bool DUMP>
+__global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
+    __shared__ WaveLds lds_all[WAVES];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id();
+    WaveLds& lds = lds_all[wave];
+
+    uint64_t d = (uint64_t)blockIdx.x * WAVES + wave;
+    if (!DUMP && d >= A.n_docs) return;  // whole wave exits; no workgroup barrier is used anywhere
+
+    uint64_t beg, end;
+    if (DUMP) {
+        beg = A.doc_begin;
+        end = A.doc_end;
+    } else {
+        beg = A.offsets[d];
+        end = A.offsets[d + 1];
+    }
+    const uint32_t len = (uint32_t)(end - beg);
+    const int unit = A.unit;
+    const uint32_t width = (uint32_t)A.width;
+    const uint8_t* text = A.text;
+    TextView tv;
+    tv.t32 = reinterpret_cast<const uint32_t*>(text);
+    tv.last = A.text_bytes ? ((A.text_bytes - 1) >> 2) : 0;
+
+    // ---- permutation constants: lane owns perms q*64 + lane
+    uint32_t alo[KPL], ahi[KPL], blo[KPL], bhi[KPL];
+    if (!DUMP) {
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+            uint32_t pi = q * 64 + lane;
+            uint64_t av = 1, bv = 0;
+            if ((int)pi < A.K) {
+                av = A.a[pi];
+                bv = A.b[pi];
+            }
+            alo[q] = (uint32_t)av;
+            ahi[q] = (uint32_t)(av >> 32);
+            blo[q] = (uint32_t)bv;
+            bhi[q] = (uint32_t)(bv >> 32);
+        }
+    }
+
+    // ---- is the document pure ASCII?  (char unit: boundaries are then implicit)
+    bool ascii = false;
+    if (unit == MDD_UNIT_CHAR) {
+        uint32_t acc = 0;
+        if (len) {
+            uint64_t d0 = beg >> 2, d1 = (end - 1) >> 2;  // dwords touching the doc (may include neighbours: conservative)
+            for (uint64_t i = d0 + lane; i <= d1; i += 64) acc |= tv.t32[i];
+        }
+        ascii = __ballot((acc & 0x80808080u) != 0u) == 0ull;
+    }
+
+    uint32_t m[KPL];
+    uint32_t n_sh_total = 0;
+
+    for (int pass = 0; pass < 2; pass++) {
+        const bool exact = pass == 1;  // pass 1 only runs if the fast permute could not prove exactness
+#pragma unroll
+        for (int q = 0; q < KPL; q++) m[q] = 0xFFFFFFFFu;
+
+        // ring state (wave-uniform)
+        uint32_t n_entS = 0, n_entE = 0, pos = 0;
+        bool scan_done = false;
+        const uint32_t look = unit == MDD_UNIT_CHAR ? width : width - 1;
+        uint32_t n_done = 0;
+        const uint32_t ascii_total = (ascii && len >= width) ? len - width + 1 : 0;
+
+        for (;;) {
+            uint32_t nvalid;
+            uint64_t s = 0;
+            uint32_t L = 0;
+            if (ascii) {
+                uint32_t rest = ascii_total - n_done;
+                nvalid = rest < 64u ? rest : 64u;
+                if (nvalid == 0) break;
+                uint32_t j = n_done + (lane < nvalid ? lane : 0u);
+                s = beg + j;
+                L = width;
+            } else {
+                // ---- fill the boundary ring until a full round is available or the doc ends
+                for (;;) {
+                    uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
+                    if (scan_done || n_ent - n_done >= 64u + look) break;
+                    // window = doc-relative bytes [pos, pos+256); lane handles 4 of them
+                    uint32_t p0 = pos + 4u * lane;
+                    uint32_t fs = 0, fe = 0;
+                    if (unit == MDD_UNIT_CHAR) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t p = p0 + k;
+                            if (p < len && (text[beg + p] & 0xC0u) != 0x80u) fs |= 1u << k;
+                        }
+                    } else {
+                        bool prev_sp = (p0 == 0 || p0 > len) ? true : text[beg + p0 - 1] == 0x20;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t p = p0 + k;
+                            bool in = p < len;
+                            bool sp = in ? text[beg + p] == 0x20 : true;
+                            bool next_sp = (p + 1 < len) ? text[beg + p + 1] == 0x20 : true;
+                            if (in && !sp && prev_sp) fs |= 1u << k;
+                            if (in && !sp && next_sp) fe |= 1u << k;
+                            prev_sp = sp;
+                        }
+                    }
+                    // ranks in byte order: 4 ballots (one per byte slot)
+                    uint32_t rank_s = 0, tot_s = 0, rank_e = 0, tot_e = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint64_t bs = __ballot((fs >> k) & 1u);
+                        rank_s += below(bs);
+                        tot_s += (uint32_t)__popcll(bs);
+                        if (unit != MDD_UNIT_CHAR) {
+                            uint64_t be = __ballot((fe >> k) & 1u);
+                            rank_e += below(be);
+                            tot_e += (uint32_t)__popcll(be);
+                        }
+                    }
+                    uint32_t rs = n_entS + rank_s, re = n_entE + rank_e;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if ((fs >> k) & 1u) lds.ringS[(rs++) & (RING - 1)] = p0 + k;
+                        if (unit != MDD_UNIT_CHAR && ((fe >> k) & 1u)) lds.ringE[(re++) & (RING - 1)] = p0 + k + 1;
+                    }
+                    n_entS += tot_s;
+                    n_entE += tot_e;
+                    pos += 256u;
+                    if (pos >= len) {
+                        scan_done = true;
+                        if (unit == MDD_UNIT_CHAR) {  // sentinel: end of the last code point
+                            if (lane == 0) lds.ringS[n_entS & (RING - 1)] = len;
+                            n_entS += 1;
+                        }
+                    }
+                }
+                wave_sync();
+                uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
+                uint32_t rest = n_ent > n_done + look ? n_ent - look - n_done : 0u;
+                nvalid = rest < 64u ? rest : 64u;
+                if (nvalid == 0) break;
+                uint32_t j = n_done + (lane < nvalid ? lane : 0u);
+                uint32_t sb = lds.ringS[j & (RING - 1)];
+                uint32_t eb = unit == MDD_UNIT_CHAR ? lds.ringS[(j + look) & (RING - 1)]
+                                                    : lds.ringE[(j + look) & (RING - 1)];
+                s = beg + sb;
+                L = eb - sb;
+            }
+
+            uint32_t Lmax = uni(wave_max(L));
+            uint32_t h = hash_any(tv, s, L, Lmax);
+
+            if (DUMP) {
+                uint64_t o = (uint64_t)n_done + lane;
+                if (lane < nvalid && o < A.dump_cap) A.dump[o] = h;
+            } else {
+                // lanes >= nvalid duplicate lane 0's shingle: harmless for a min
+                wave_sync();
+                lds.hbuf[lane] = h;
+                wave_sync();
+                const uint32_t n4 = (nvalid + 3u) >> 2;
+                const uint4* hb4 = reinterpret_cast<const uint4*>(lds.hbuf);
+                if (!exact) {
+                    // fast form: t' = a*h + (b+1) mod 2^64 ; s = lo32(t') + (t' >> 61).
+                    // If s > 8 then s - 1 is exactly ((a*h+b) mod 2^64) mod (2^61-1) & 0xFFFFFFFF
+                    // (proof in DESIGN.md); a minimum <= 8 sends the document to the exact pass.
+                    for (uint32_t i = 0; i < n4; i++) {
+                        uint4 hv = hb4[i];
+                        uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+#pragma unroll
+                            for (int q = 0; q < KPL; q++) {
+                                uint64_t b1 = (((uint64_t)bhi[q] << 32) | blo[q]) + 1ull;
+                                uint64_t t = (uint64_t)alo[q] * hh[e] + b1;
+                                uint32_t thi = (uint32_t)(t >> 32) + ahi[q] * hh[e];
+                                uint32_t sv = (uint32_t)t + (thi >> 29);
+                                m[q] = sv < m[q] ? sv : m[q];
+                            }
+                        }
+                    }
+                } else {
+                    for (uint32_t i = 0; i < n4; i++) {
+                        uint4 hv = hb4[i];
+                        uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+#pragma unroll
+                            for (int q = 0; q < KPL; q++) {
+                                uint64_t av = ((uint64_t)ahi[q] << 32) | alo[q];
+                                uint64_t bv = ((uint64_t)bhi[q] << 32) | blo[q];
+                                uint64_t t = av * (uint64_t)hh[e] + bv;  // wraps mod 2^64 like numpy uint64
+                                uint64_t x = (t & P61) + (t >> 61);
+                                if (x >= P61) x -= P61;
+                                uint32_t r = (uint32_t)x;
+                                m[q] = r < m[q] ? r : m[q];
+                            }
+                        }
+                    }
+                }
+            }
+            n_done += nvalid;
+        }
+        n_sh_total = n_done;
+
+        if (DUMP) break;
+        if (exact) break;
+        bool risky = false;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) risky |= (m[q] <= FAST_GUARD);
+        if (n_sh_total == 0 || __ballot(risky) == 0ull) {
+#pragma unroll
+            for (int q = 0; q < KPL; q++) m[q] = n_sh_total ? m[q] - 1u : 0xFFFFFFFFu;
+            break;
+        }
+    }
+
+    if (DUMP) {
+        if (lane == 0 && wave == 0 && blockIdx.x == 0) *A.dump_n = n_sh_total;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < KPL; q++) {
+        uint32_t pi = q * 64 + lane;
+        if ((int)pi < A.K) A.sig[d * (uint64_t)A.K + pi] = m[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// band keys, routing, bucketing, union-find (HBM-bound; one thread per record / document)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t tuple_key(const uint32_t* t, int rows, uint32_t band, int key_bits) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)band * 0xD6E8FEB86659FD93ULL);
+    for (int i = 0; i < rows; i++) h = mix64(h ^ t[i]) + 0x9E3779B97F4A7C15ULL;
+    h = mix64(h);
+    if (key_bits < 64) h &= (1ULL << key_bits) - 1;
+    return h ? h : 1ULL;  // 0 marks an empty table slot
+}
+
+__global__ void __launch_bounds__(256) band_keys_kernel(const uint32_t* sig, uint64_t n_docs, int K, int bands, int rows,
+                                                        uint64_t doc_base, int key_bits, uint64_t* key, uint64_t* meta) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t n_rec = n_docs * (uint64_t)bands;
+    if (i >= n_rec) return;
+    uint64_t d = i / bands;
+    uint32_t j = (uint32_t)(i % bands);
+    key[i] = tuple_key(sig + d * (uint64_t)K + (uint64_t)j * rows, rows, j, key_bits);
+    meta[i] = ((uint64_t)j << 56) | (doc_base + d);
+}
+
+__global__ void __launch_bounds__(256) packed_keys_kernel(const uint32_t* tuples, const uint64_t* meta, uint64_t n_rec,
+                                                          int rows, int key_bits, uint64_t* key) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    key[i] = tuple_key(tuples + i * (uint64_t)rows, rows, (uint32_t)(meta[i] >> 56), key_bits);
+}
+
+__device__ __forceinline__ uint32_t route_of(uint64_t key, int world) { return (uint32_t)((key >> 32) % (uint64_t)world); }
+
+__global__ void __launch_bounds__(256) route_count_kernel(const uint64_t* key, uint64_t n_rec, int world,
+                                                          unsigned long long* counts) {
+    __shared__ unsigned int loc[64];
+    if (threadIdx.x < 64) loc[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rec) atomicAdd(&loc[route_of(key[i], world)], 1u);
+    __syncthreads();
+    if (threadIdx.x < (unsigned)world && loc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)loc[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) route_pack_kernel(const uint32_t* sig, int K, int bands, int rows, const uint64_t* key,
+                                                         const uint64_t* meta, uint64_t n_rec, int world,
+                                                         unsigned long long* cursor, uint32_t* tuples_out,
+                                                         uint64_t* meta_out) {
+    __shared__ unsigned int loc[64];
+    __shared__ unsigned long long basep[64];
+    if (threadIdx.x < 64) loc[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = 0, slot = 0;
+    if (i < n_rec) {
+        r = route_of(key[i], world);
+        slot = atomicAdd(&loc[r], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)world && loc[threadIdx.x])
+        basep[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)loc[threadIdx.x]);
+    __syncthreads();
+    if (i < n_rec) {
+        uint64_t o = basep[r] + slot;
+        uint64_t d = i / bands;
+        uint32_t j = (uint32_t)(i % bands);
+        const uint32_t* t = sig + d * (uint64_t)K + (uint64_t)j * rows;
+        for (int k = 0; k < rows; k++) tuples_out[o * rows + k] = t[k];
+        meta_out[o] = meta[i];
+    }
+}
+
+struct TupleAddr {
+    const uint32_t* base;
+    uint64_t rec_per_doc, doc_stride, band_stride;
+    int rows;
+    __device__ __forceinline__ const uint32_t* at(uint64_t i) const {
+        return base + (i / rec_per_doc) * doc_stride + (i % rec_per_doc) * band_stride;
+    }
+};
+
+__global__ void __launch_bounds__(256) bucket_insert_kernel(const uint64_t* key, uint64_t n_rec, unsigned long long* tab_key,
+                                                            uint32_t* tab_rep, uint64_t tab_mask) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    unsigned long long k = key[i];
+    uint64_t slot = mix64(k) & tab_mask;
+    for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: table is never full (size >= 2*n_rec)
+        unsigned long long cur = atomicCAS(&tab_key[slot], 0ULL, k);
+        if (cur == 0ULL || cur == k) {
+            atomicMin(&tab_rep[slot], (uint32_t)i);
+            return;
+        }
+        slot = (slot + 1) & tab_mask;
+    }
+}
+
+__device__ __forceinline__ void append_edge(uint32_t u, uint32_t v, bool have, uint32_t* edge_u, uint32_t* edge_v,
+                                            uint64_t cap, unsigned long long* n_edges) {
+    // wave-aggregated append: one atomic per wave
+    uint64_t bal = __ballot(have);
+    if (bal == 0) return;
+    uint32_t cnt = (uint32_t)__popcll(bal);
+    uint32_t rank = below(bal);
+    unsigned long long base = 0;
+    int leader = __ffsll((unsigned long long)bal) - 1;
+    if ((int)lane_id() == leader) base = atomicAdd(n_edges, (unsigned long long)cnt);
+    base = ((unsigned long long)__shfl((int)(base >> 32), leader, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, leader, 64);
+    if (have) {
+        uint64_t o = base + rank;
+        if (o < cap) {
+            edge_u[o] = u;
+            edge_v[o] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) bucket_link_kernel(const uint64_t* key, const uint64_t* meta, uint64_t n_rec, TupleAddr ta,
+                                                          const unsigned long long* tab_key, const uint32_t* tab_rep,
+                                                          uint64_t tab_mask, uint32_t* edge_u, uint32_t* edge_v,
+                                                          uint64_t edge_cap, unsigned long long* n_edges, uint64_t* coll_idx,
+                                                          uint64_t coll_cap, unsigned long long* n_coll, uint64_t* rec_bucket) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool have = false;
+    uint32_t eu = 0, ev = 0;
+    if (i < n_rec) {
+        unsigned long long k = key[i];
+        uint64_t slot = mix64(k) & tab_mask;
+        uint32_t rep = (uint32_t)i;
+        for (uint64_t probe = 0; probe <= tab_mask; probe++) {
+            unsigned long long cur = tab_key[slot];
+            if (cur == k) {
+                rep = tab_rep[slot];
+                break;
+            }
+            if (cur == 0ULL) break;  // cannot happen after insert; defensive
+            slot = (slot + 1) & tab_mask;
+        }
+        if (rec_bucket) rec_bucket[i] = rep;
+        if (rep != (uint32_t)i) {
+            const uint32_t* x = ta.at(i);
+            const uint32_t* y = ta.at(rep);
+            uint64_t mi = meta[i], mr = meta[rep];
+            bool same = (mi >> 56) == (mr >> 56);
+            for (int r = 0; r < ta.rows; r++) same &= x[r] == y[r];
+            if (same) {
+                eu = (uint32_t)mi;
+                ev = (uint32_t)mr;
+                have = eu != ev;
+            } else {
+                unsigned long long o = atomicAdd(n_coll, 1ULL);
+                if (o < coll_cap) coll_idx[o] = i;
+            }
+        }
+    }
+    append_edge(eu, ev, have, edge_u, edge_v, edge_cap, n_edges);
+}
+
+__global__ void __launch_bounds__(256) iota_kernel(uint32_t* p, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ uint32_t uf_find(const uint32_t* parent, uint32_t x) {
+    // parents only ever decrease, so this walk terminates at the current root
+    for (;;) {
+        uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        x = p;
+    }
+}
+
+__global__ void __launch_bounds__(256) uf_union_kernel(uint32_t* parent, const uint32_t* eu, const uint32_t* ev, uint64_t n_edges,
+                                                       uint64_t n_docs) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_edges) return;
+    uint32_t u = eu[i], v = ev[i];
+    if (u >= n_docs || v >= n_docs) return;
+    for (;;) {  // lock-free: always hang the larger root under the smaller one
+        u = uf_find(parent, u);
+        v = uf_find(parent, v);
+        if (u == v) return;
+        uint32_t hi = u > v ? u : v, lo = u > v ? v : u;
+        uint32_t old = atomicCAS(&parent[hi], hi, lo);
+        if (old == hi) return;
+        u = old;  // hi was re-parented meanwhile: retry from its new parent
+        v = lo;
+    }
+}
+
+__global__ void __launch_bounds__(256) uf_flatten_kernel(uint32_t* parent, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = uf_find(parent, (uint32_t)i);
+    __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256) removed_kernel(const uint32_t* labels, uint64_t first, uint64_t n, uint8_t* removed,
+                                                      unsigned long long* n_removed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool rm = false;
+    if (i < n) {
+        rm = labels[first + i] != (uint32_t)(first + i);
+        removed[i] = rm ? 1 : 0;
+    }
+    uint64_t bal = __ballot(rm);
+    if (bal && lane_id() == (uint32_t)(__ffsll((unsigned long long)bal) - 1)) atomicAdd(n_removed, (unsigned long long)__popcll(bal));
+}
+
+// VALU calibration: dependency-free fast-class int32 ops (v_xor / v_add / v_lshrrev)
+__global__ void __launch_bounds__(256) valu_cal_kernel(uint32_t* out, int iters, uint32_t seed) {
+    uint32_t acc[8];
+    uint32_t x = threadIdx.x * 2654435761u + seed;
+    for (int c = 0; c < 8; c++) acc[c] = x + c * 977u;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(acc[c]) : "v"(x));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(acc[c]) : "v"(x));
+            }
+        }
+    }
+    uint32_t r = 0;
+    for (int c = 0; c < 8; c++) r ^= acc[c];
+    if (r == 0x12345678u) out[0] = r;
+}
+
+inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+int check_sig_common(const char* fn, mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, int unit, int width) {
+    REQUIRE(ctx != nullptr, "%s: ctx is NULL", fn);
+    REQUIRE(unit == MDD_UNIT_CHAR || unit == MDD_UNIT_WORD, "%s: unknown unit %d", fn, unit);
+    REQUIRE(width >= 1 && width <= 128, "%s: width=%d outside [1,128]", fn, width);
+    REQUIRE(text != nullptr || text_bytes == 0, "%s: text is NULL", fn);
+    REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "%s: text must be 4-byte aligned", fn);
+    return MDD_OK;
+}
+
+template <bool DUMP>
+int launch_sig(mdd_ctx* ctx, const SigArgs& A, unsigned grid) {
+    int kpl = DUMP ? 1 : (A.K + 63) / 64;
+    dim3 g(grid), b(64 * WAVES);
+    switch (kpl) {
+        case 1: hipLaunchKernelGGL((sig_kernel<1, DUMP>), g, b, 0, ctx->stream, A); break;
+        case 2: hipLaunchKernelGGL((sig_kernel<2, DUMP>), g, b, 0, ctx->stream, A); break;
+        case 3: hipLaunchKernelGGL((sig_kernel<3, DUMP>), g, b, 0, ctx->stream, A); break;
+        case 4: hipLaunchKernelGGL((sig_kernel<4, DUMP>), g, b, 0, ctx->stream, A); break;
+        default: return fail(MDD_ERR_UNSUPPORTED, "K=%d needs %d perms per lane (max 4)", A.K, kpl);
+    }
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int mdd_version(void) { return 100; }
+
+const char* mdd_last_error(void) { return g_err; }
+
+int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
+    REQUIRE(out != nullptr, "mdd_ctx_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MDD_ERR_HIP, "mdd_ctx_create: no usable HIP device (%s); libmdd_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    REQUIRE(device >= 0 && device < n, "mdd_ctx_create: device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MDD_ERR_UNSUPPORTED, "mdd_ctx_create: device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    mdd_ctx* c = new mdd_ctx();
+    c->device = device;
+    c->cus = prop.multiProcessorCount;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->owns_stream = false;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete c;
+            return fail(MDD_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se));
+        }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return MDD_OK;
+}
+
+int mdd_ctx_destroy(mdd_ctx* ctx) {
+    if (!ctx) return MDD_OK;
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MDD_OK;
+}
+
+int mdd_ctx_sync(mdd_ctx* ctx) {
+    REQUIRE(ctx != nullptr, "mdd_ctx_sync: ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MDD_OK;
+}
+
+int mdd_make_perms(uint32_t seed, int K, uint64_t* a_host, uint64_t* b_host) {
+    REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "mdd_make_perms: K=%d outside [1,%d]", K, MDD_MAX_PERM);
+    REQUIRE(a_host && b_host, "mdd_make_perms: NULL output");
+    Mt19937 g(seed);
+    for (int i = 0; i < K; i++) {
+        a_host[i] = g.randint(1, P61);
+        b_host[i] = g.randint(0, P61);
+    }
+    return MDD_OK;
+}
+
+int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                   int unit, int width, int K, const uint64_t* a, const uint64_t* b, uint32_t* sig_out) {
+    int rc = check_sig_common("mdd_signatures", ctx, text, text_bytes, unit, width);
+    if (rc) return rc;
+    REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "mdd_signatures: K=%d outside [1,%d]", K, MDD_MAX_PERM);
+    REQUIRE(offsets && a && b && sig_out, "mdd_signatures: NULL pointer argument");
+    REQUIRE(n_docs <= 0x7FFFFFFFull * WAVES, "mdd_signatures: n_docs=%llu too large for one launch",
+            (unsigned long long)n_docs);
+    if (n_docs == 0) return MDD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    SigArgs A{};
+    A.text = text;
+    A.text_bytes = text_bytes;
+    A.offsets = offsets;
+    A.n_docs = n_docs;
+    A.unit = unit;
+    A.width = width;
+    A.K = K;
+    A.a = a;
+    A.b = b;
+    A.sig = sig_out;
+    return launch_sig<false>(ctx, A, grid_for(n_docs, WAVES));
+}
+
+int mdd_shingle_hashes(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, uint64_t doc_begin, uint64_t doc_end,
+                       int unit, int width, uint32_t* out, uint64_t cap, uint64_t* n_out) {
+    int rc = check_sig_common("mdd_shingle_hashes", ctx, text, text_bytes, unit, width);
+    if (rc) return rc;
+    REQUIRE(doc_begin <= doc_end && doc_end <= text_bytes, "mdd_shingle_hashes: document range outside text");
+    REQUIRE(doc_end - doc_begin < (1ull << 29), "mdd_shingle_hashes: document too long");
+    REQUIRE(n_out && (out || cap == 0), "mdd_shingle_hashes: NULL output");
+    HIP_TRY(hipSetDevice(ctx->device));
+    SigArgs A{};
+    A.text = text;
+    A.text_bytes = text_bytes;
+    A.unit = unit;
+    A.width = width;
+    A.K = 1;
+    A.doc_begin = doc_begin;
+    A.doc_end = doc_end;
+    A.dump = out;
+    A.dump_cap = cap;
+    A.dump_n = n_out;
+    A.n_docs = 1;
+    return launch_sig<true>(ctx, A, 1);
+}
+
+int mdd_band_keys(mdd_ctx* ctx, const uint32_t* sig, uint64_t n_docs, int K, int bands, int rows, uint64_t doc_base,
+                  int key_bits, uint64_t* key, uint64_t* meta) {
+    REQUIRE(ctx && sig && key && meta, "mdd_band_keys: NULL argument");
+    REQUIRE(bands >= 1 && bands <= MDD_MAX_BANDS && rows >= 1 && (int64_t)bands * rows <= K,
+            "mdd_band_keys: bands=%d rows=%d do not fit K=%d", bands, rows, K);
+    REQUIRE(key_bits >= 1 && key_bits <= 64, "mdd_band_keys: key_bits=%d outside [1,64]", key_bits);
+    REQUIRE(doc_base + n_docs <= 0xFFFFFFFFull, "mdd_band_keys: global document index exceeds 2^32-1");
+    uint64_t n_rec = n_docs * (uint64_t)bands;
+    if (n_rec == 0) return MDD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(band_keys_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, sig, n_docs, K, bands, rows,
+                       doc_base, key_bits, key, meta);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_packed_keys(mdd_ctx* ctx, const uint32_t* tuples, const uint64_t* meta, uint64_t n_rec, int rows, int key_bits,
+                    uint64_t* key) {
+    REQUIRE(ctx && key, "mdd_packed_keys: NULL argument");
+    REQUIRE(rows >= 1 && key_bits >= 1 && key_bits <= 64, "mdd_packed_keys: bad rows/key_bits");
+    if (n_rec == 0) return MDD_OK;
+    REQUIRE(tuples && meta, "mdd_packed_keys: NULL records");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(packed_keys_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, tuples, meta, n_rec, rows,
+                       key_bits, key);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_route_count(mdd_ctx* ctx, const uint64_t* key, uint64_t n_rec, int world, uint64_t* counts) {
+    REQUIRE(ctx && counts, "mdd_route_count: NULL argument");
+    REQUIRE(world >= 1 && world <= 64, "mdd_route_count: world=%d outside [1,64]", world);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint64_t) * world, ctx->stream));
+    if (n_rec == 0) return MDD_OK;
+    REQUIRE(key != nullptr, "mdd_route_count: key is NULL");
+    hipLaunchKernelGGL(route_count_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, key, n_rec, world,
+                       reinterpret_cast<unsigned long long*>(counts));
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows, const uint64_t* key, const uint64_t* meta,
+                   uint64_t n_rec, int world, uint64_t* send_cursor, uint32_t* tuples_out, uint64_t* meta_out) {
+    REQUIRE(ctx && send_cursor, "mdd_route_pack: NULL argument");
+    REQUIRE(world >= 1 && world <= 64, "mdd_route_pack: world=%d outside [1,64]", world);
+    REQUIRE(bands >= 1 && rows >= 1 && (int64_t)bands * rows <= K, "mdd_route_pack: bands/rows do not fit K");
+    if (n_rec == 0) return MDD_OK;
+    REQUIRE(sig && key && meta && tuples_out && meta_out, "mdd_route_pack: NULL records");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(route_pack_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, sig, K, bands, rows, key, meta,
+                       n_rec, world, reinterpret_cast<unsigned long long*>(send_cursor), tuples_out, meta_out);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, uint64_t n_rec, const uint32_t* tuple_base,
+                     uint64_t rec_per_doc, uint64_t doc_stride, uint64_t band_stride, int rows, uint64_t* tab_key,
+                     uint32_t* tab_rep, uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap,
+                     uint64_t* n_edges, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll, uint64_t* rec_bucket) {
+    REQUIRE(ctx && n_edges && n_coll, "mdd_bucket_edges: NULL counter");
+    REQUIRE(n_rec <= 0xFFFFFFFEull, "mdd_bucket_edges: n_rec=%llu exceeds 2^32-2", (unsigned long long)n_rec);
+    REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_rec,
+            "mdd_bucket_edges: tab_size=%llu must be a power of two >= 2*n_rec", (unsigned long long)tab_size);
+    REQUIRE(rec_per_doc >= 1 && rows >= 1, "mdd_bucket_edges: bad tuple addressing");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(n_edges, 0, sizeof(uint64_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(n_coll, 0, sizeof(uint64_t), ctx->stream));
+    if (n_rec == 0) return MDD_OK;
+    REQUIRE(key && meta && tuple_base && tab_key && tab_rep && (edge_cap == 0 || (edge_u && edge_v)) &&
+                (coll_cap == 0 || coll_idx),
+            "mdd_bucket_edges: NULL buffer");
+    HIP_TRY(hipMemsetAsync(tab_key, 0, sizeof(uint64_t) * tab_size, ctx->stream));
+    HIP_TRY(hipMemsetAsync(tab_rep, 0xFF, sizeof(uint32_t) * tab_size, ctx->stream));
+    unsigned g = grid_for(n_rec, 256);
+    hipLaunchKernelGGL(bucket_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key, n_rec,
+                       reinterpret_cast<unsigned long long*>(tab_key), tab_rep, tab_size - 1);
+    HIP_TRY(hipGetLastError());
+    TupleAddr ta{tuple_base, rec_per_doc, doc_stride, band_stride, rows};
+    hipLaunchKernelGGL(bucket_link_kernel, dim3(g), dim3(256), 0, ctx->stream, key, meta, n_rec, ta,
+                       reinterpret_cast<const unsigned long long*>(tab_key), tab_rep, tab_size - 1, edge_u, edge_v, edge_cap,
+                       reinterpret_cast<unsigned long long*>(n_edges), coll_idx, coll_cap,
+                       reinterpret_cast<unsigned long long*>(n_coll), rec_bucket);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_components_init(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs) {
+    REQUIRE(ctx && (labels || n_docs == 0), "mdd_components_init: NULL argument");
+    REQUIRE(n_docs <= 0xFFFFFFFFull, "mdd_components_init: n_docs exceeds 2^32-1");
+    if (n_docs == 0) return MDD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_components_union(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs, const uint32_t* edge_u, const uint32_t* edge_v,
+                         uint64_t n_edges) {
+    REQUIRE(ctx != nullptr, "mdd_components_union: ctx is NULL");
+    if (n_edges == 0 || n_docs == 0) return MDD_OK;
+    REQUIRE(labels && edge_u && edge_v, "mdd_components_union: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(uf_union_kernel, dim3(grid_for(n_edges, 256)), dim3(256), 0, ctx->stream, labels, edge_u, edge_v, n_edges,
+                       n_docs);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_components_finish(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs) {
+    REQUIRE(ctx && (labels || n_docs == 0), "mdd_components_finish: NULL argument");
+    if (n_docs == 0) return MDD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(uf_flatten_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint64_t n, uint8_t* removed,
+                     uint64_t* n_removed) {
+    REQUIRE(ctx && n_removed, "mdd_removed_mask: NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(n_removed, 0, sizeof(uint64_t), ctx->stream));
+    if (n == 0) return MDD_OK;
+    REQUIRE(labels && removed, "mdd_removed_mask: NULL buffer");
+    hipLaunchKernelGGL(removed_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, labels, first, n, removed,
+                       reinterpret_cast<unsigned long long*>(n_removed));
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_valu_calibrate(mdd_ctx* ctx, int iters, double* tops_host) {
+    REQUIRE(ctx && tops_host && iters > 0, "mdd_valu_calibrate: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t* out = nullptr;
+    HIP_TRY(hipMalloc(&out, 256));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    unsigned blocks = (unsigned)ctx->cus * 8;
+    hipLaunchKernelGGL(valu_cal_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, 64, 1u);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(valu_cal_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, iters, 1u);
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(out);
+    double ops = (double)blocks * 256.0 * (double)iters * 4 * 8 * 2;
+    *tops_host = ops / (best * 1e-3) / 1e12;
+    return MDD_OK;
+}
+
+}  // extern "C"

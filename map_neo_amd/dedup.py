@@ -1,0 +1,131 @@
+"""Whole-path drivers: signatures -> band records -> buckets/edges -> components -> removed.
+
+`dedup_local`       one GPU, everything stays in HBM.
+`dedup_distributed` one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI):
+                    documents are sharded by contiguous global index range, band records are
+                    routed to their owner rank with an all-to-all so that every (band, tuple)
+                    bucket lives on ONE GPU (EN:136's groupBy shuffle, ZH-1:58-61's per-band
+                    directories), the edges every rank finds are all-gathered and every rank
+                    runs the same union-find, so labels are identical on all ranks and equal
+                    to the one-GPU result.
+
+Both take a `backend` object implementing the stage methods of minhash.Engine.  The product
+backend is Engine (HIP); tests may inject another backend to exercise the sharding / exchange
+logic on CPU with gloo.  Nothing in this module computes a hash or a signature itself.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .minhash import BANDS, NUM_PERM, ROWS, SEED, WIDTH, as_u32, as_u64, resolve_collisions
+
+
+def _resolve_sig_layout(be, coll_idx, sig, meta, bands, rows):
+    if coll_idx.size == 0:
+        return None
+    meta_h = as_u64(meta)
+    K = sig.shape[1]
+    sig_h = as_u32(sig)
+
+    def tuple_of(i):
+        d, j = divmod(i, bands)
+        return sig_h[d, j * rows:(j + 1) * rows].tobytes()
+
+    return resolve_collisions(coll_idx, meta_h, tuple_of)
+
+
+def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = NUM_PERM, width: int = WIDTH,
+                unit: str = "char", bands: int = BANDS, rows: int = ROWS, seed: int = SEED,
+                text_bytes: Optional[int] = None, key_bits: int = 64, want_buckets: bool = False):
+    """One-GPU path.  Returns a dict of device tensors: sig [n,K], edge_u/edge_v, labels [n]
+    (label = smallest doc index of the component), removed [n] uint8, n_removed (device
+    int64[1]), n_collisions (host int)."""
+    n = offsets.numel() - 1
+    sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
+    key, meta = be.band_keys(sig, bands, rows, 0, key_bits)
+    eu, ev, coll_idx, rb = be.bucket_edges(key, meta, sig, bands, num_perm, rows, rows, want_buckets)
+    labels = be.components_init(n)
+    be.components_union(labels, eu, ev)
+    extra = _resolve_sig_layout(be, coll_idx, sig, meta, bands, rows)
+    if extra is not None and extra[0].size:
+        xu, xv = be.to_device(extra[0]), be.to_device(extra[1])
+        be.components_union(labels, xu, xv)
+        eu, ev = torch.cat([eu, xu]), torch.cat([ev, xv])
+    be.components_finish(labels)
+    removed, n_removed = be.removed_mask(labels, 0, n)
+    return {"sig": sig, "key": key, "meta": meta, "edge_u": eu, "edge_v": ev, "labels": labels,
+            "removed": removed, "n_removed": n_removed, "n_collisions": int(coll_idx.size),
+            "rec_bucket": rb}
+
+
+def _all_to_all_v(t: torch.Tensor, send_counts, recv_counts, width: int, group=None):
+    import torch.distributed as dist
+    out = torch.empty(int(sum(recv_counts)) * width, dtype=t.dtype, device=t.device)
+    dist.all_to_all_single(out, t, [int(c) * width for c in recv_counts], [int(c) * width for c in send_counts],
+                           group=group)
+    return out
+
+
+def _all_gather_v(t: torch.Tensor, group=None):
+    """All-gather of variable-length 1-D tensors (sizes exchanged first)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:s] for o, s in zip(outs, sizes)])
+
+
+def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: int, n_global: int,
+                      num_perm: int = NUM_PERM, width: int = WIDTH, unit: str = "char", bands: int = BANDS,
+                      rows: int = ROWS, seed: int = SEED, text_bytes: Optional[int] = None, key_bits: int = 64,
+                      group=None, timings: Optional[dict] = None):
+    """Multi-GPU path; every rank calls it with its own shard (documents doc_base ..
+    doc_base+n_local of n_global).  Returns the same dict as dedup_local; labels cover all
+    n_global documents (replicated), removed covers the local shard."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n_local = offsets.numel() - 1
+    sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
+    key, meta = be.band_keys(sig, bands, rows, doc_base, key_bits)
+    # --- route band records to their owner rank (all-to-all over xGMI)
+    tuples_s, meta_s, send_counts = be.route(sig, key, meta, bands, rows, world)
+    send_counts = [int(c) for c in send_counts.tolist()]
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=meta_s.device)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(c) for c in rc.tolist()]
+    tuples_r = _all_to_all_v(tuples_s, send_counts, recv_counts, rows, group)
+    meta_r = _all_to_all_v(meta_s, send_counts, recv_counts, 1, group)
+    # --- local buckets over the records this rank owns
+    key_r = be.packed_keys(tuples_r, meta_r, rows, key_bits)
+    eu, ev, coll_idx, _ = be.bucket_edges(key_r, meta_r, tuples_r, 1, rows, 0, rows, False)
+    if coll_idx.size:
+        meta_h = as_u64(meta_r)
+        tup_h = as_u32(tuples_r).reshape(-1, rows)
+        xu, xv = resolve_collisions(coll_idx, meta_h, lambda i: tup_h[i].tobytes())
+        if xu.size:
+            eu, ev = torch.cat([eu, be.to_device(xu)]), torch.cat([ev, be.to_device(xv)])
+    # --- merge: all-gather every rank's edges, identical union-find everywhere
+    eu_all = _all_gather_v(eu, group)
+    ev_all = _all_gather_v(ev, group)
+    labels = be.components_init(n_global)
+    be.components_union(labels, eu_all, ev_all)
+    be.components_finish(labels)
+    removed, n_removed = be.removed_mask(labels, doc_base, n_local)
+    if timings is not None:
+        timings["records_sent"] = int(sum(send_counts))
+        timings["records_received"] = int(sum(recv_counts))
+        timings["edges_local"] = int(eu.numel())
+        timings["edges_global"] = int(eu_all.numel())
+    return {"sig": sig, "edge_u": eu_all, "edge_v": ev_all, "labels": labels, "removed": removed,
+            "n_removed": n_removed, "n_collisions": int(coll_idx.size)}

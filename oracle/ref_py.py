@@ -214,8 +214,13 @@ def star_edges(doc_id_list: Sequence) -> List[tuple]:
 
 # --------------------------------------------------------------------------- a12
 def large_star_small_star(edges: Iterable[tuple]) -> set:
-    """EN:82-115,138-144: literal alternating large-star / small-star loop; returns the
-    converged edge set {(v, min(component))}.  Small inputs only (pure Python)."""
+    """EN:82-115,138-144: literal alternating large-star / small-star loop with the
+    reference's own stopping rule (EN:142 compares the small-star output with the large-star
+    output of the SAME iteration).  That rule can stop one large-star early, so the returned
+    edge set is not always the pure star {(v, min(component))}; what IS guaranteed at a
+    small-star fixpoint is that every non-minimum node of a component has a smaller neighbour,
+    i.e. {x[0] for x in result} == all non-minimum members == remove_list of EN:145.
+    Small inputs only (pure Python)."""
     a = set(edges)
     while True:
         nb: dict = {}

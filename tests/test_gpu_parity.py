@@ -1,0 +1,207 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+Bit-exact is the bar everywhere (integer / byte / index work)."""
+import numpy as np
+import pytest
+import torch
+
+from map_neo_amd import corpus
+from map_neo_amd.dedup import dedup_local
+from map_neo_amd.minhash import as_u32, as_u64, pack_texts
+from oracle import ref_c as RC
+from oracle import ref_py as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(engine, docs):
+    buf, offs = pack_texts(docs)
+    return engine.to_device(buf), engine.to_device(offs), buf, offs
+
+
+def test_shingle_hashes_stage(engine, mini_docs):
+    """a2+a3: every shingle's sha1_hash32, in order, for ASCII / CJK / emoji / mixed docs."""
+    text, offs_d, buf, offs = _dev(engine, mini_docs)
+    nbytes = int(offs[-1])
+    idx = list(range(0, 20)) + list(range(55, 125, 7)) + [198, 199]
+    for unit, width in (("char", 13), ("char", 1), ("char", 20), ("char", 40), ("word", 5), ("word", 1), ("word", 12)):
+        for i in idx:
+            b, e = int(offs[i]), int(offs[i + 1])
+            got = engine.shingle_hashes(text, nbytes, b, e, width, unit)
+            exp = RC.shingle_hashes(bytes(buf[b:e]), width, unit)
+            assert got.shape == exp.shape, (unit, width, i)
+            assert (got == exp).all(), (unit, width, i)
+
+
+@pytest.mark.parametrize("name,K,width,unit", [("sig_char13_K256", 256, 13, "char"), ("sig_word5_K128", 128, 5, "word"),
+                                               ("sig_char5_K128", 128, 5, "char"), ("sig_char20_K64", 64, 20, "char")])
+def test_signatures_golden(engine, mini_docs, mini_expected, name, K, width, unit):
+    text, offs_d, _, _ = _dev(engine, mini_docs)
+    sig = as_u32(engine.signatures(text, offs_d, K, width, unit))
+    assert (sig == mini_expected[name]).all()
+
+
+def test_signatures_reference_config_and_prefix(engine, mini_docs, mini_expected):
+    """(char, 13, K=128) is the reference's configuration; K=128 == first 128 columns of K=256."""
+    text, offs_d, _, _ = _dev(engine, mini_docs)
+    s128 = as_u32(engine.signatures(text, offs_d, 128, 13, "char"))
+    assert (s128 == mini_expected["sig_char13_K256"][:, :128]).all()
+    for K in (1, 63, 65, 100, 192, 200):
+        sk = as_u32(engine.signatures(text, offs_d, K, 13, "char"))
+        assert (sk == mini_expected["sig_char13_K256"][:, :K]).all(), K
+
+
+def test_signatures_random_utf8(engine):
+    """random code points of 1..4 utf-8 bytes, ragged lengths incl. 0 and < width, unaligned starts"""
+    rng = np.random.Generator(np.random.PCG64(11))
+    pools = [(0x20, 0x7F), (0x80, 0x7FF), (0x800, 0xD7FF), (0x10000, 0x10FFFF)]
+    docs = []
+    for i in range(300):
+        n = int(rng.integers(0, 400)) if i % 5 else int(rng.integers(0, 15))
+        mix = rng.integers(0, 4, n) if i % 3 else np.full(n, i % 4)
+        cps = [int(rng.integers(*pools[m])) for m in mix]
+        docs.append("".join(chr(c) for c in cps))
+    text, offs_d, buf, offs = _dev(engine, docs)
+    for K, width, unit in ((128, 13, "char"), (256, 13, "char"), (128, 3, "word"), (64, 30, "char")):
+        got = as_u32(engine.signatures(text, offs_d, K, width, unit))
+        exp = RC.signatures(buf, offs, K, width, unit)
+        assert (got == exp).all(), (K, width, unit)
+
+
+def test_signatures_synthetic_vs_oracle(engine):
+    """seeded bilingual corpus with near-duplicates, 3000 docs ~1 KB (C oracle finishes in seconds)"""
+    spec = corpus.CorpusSpec(3000, 1024, lang="mixed", dup_frac=0.2)
+    text, offs = corpus.generate(spec, device=engine.device)
+    sig = as_u32(engine.signatures(text, offs, 128))
+    exp = RC.signatures(text.cpu().numpy(), offs.cpu().numpy().astype(np.uint64), 128)
+    assert (sig == exp).all()
+
+
+def test_exact_pass_forced(engine):
+    """Permutations chosen so that x = (t & p) + (t >> 61) >= p (the rare modular-reduction
+    branch) and so that the fast form's guard (min <= 8) fires: results must still be exact."""
+    docs = ["abcdefghijklmnopqrstuvwxyz", "the quick brown fox jumps over the lazy dog", "abcdefghijklm"]
+    text, offs_d, buf, offs = _dev(engine, docs)
+    p = (1 << 61) - 1
+    hs = [int(h) for h in RC.shingle_hashes(docs[0].encode(), 13, "char")]
+    a = np.ones(128, np.uint64)
+    b = np.zeros(128, np.uint64)
+    for i in range(128):
+        h = hs[i % len(hs)]
+        k = i % 9                       # t = a*h+b = p + k - ...: land x in [p-1, p+7] and around the 2^61 boundaries
+        a[i] = 1
+        b[i] = (p - h + k - 1) % p
+    a[100:] = np.array([(1 << 61) - 2 - i for i in range(28)], np.uint64)      # large a: wrap mod 2^64 + top bits set
+    b[100:] = np.array([(1 << 61) - 2 - 3 * i for i in range(28)], np.uint64)
+    perms = (engine.to_device(a), engine.to_device(b))
+    got = as_u32(engine.signatures(text, offs_d, 128, 13, "char", perms=perms))
+    exp = RC.signatures(buf, offs, 128, 13, "char", perms=(a, b))
+    assert (got == exp).all()
+    assert (exp <= 8).any()             # the guard really was exercised
+
+
+def _partition(labels):
+    out = {}
+    for i, l in enumerate(labels.tolist()):
+        out.setdefault(l, []).append(i)
+    return out
+
+
+@pytest.mark.parametrize("b,r,K", [(9, 13, 128), (14, 9, 128), (20, 12, 256)])
+def test_dedup_golden(engine, mini_docs, mini_expected, b, r, K):
+    """whole path on the golden mini-corpus: identical buckets, labels, removed set"""
+    text, offs_d, _, _ = _dev(engine, mini_docs)
+    n = len(mini_docs)
+    out = dedup_local(engine, text, offs_d, K, 13, "char", b, r, want_buckets=True)
+    labels = as_u32(out["labels"])
+    assert (labels == mini_expected[f"labels_b{b}_r{r}_K{K}"]).all()
+    removed = out["removed"].cpu().numpy().astype(bool)
+    assert (removed == (labels != np.arange(n))).all()
+    assert int(out["n_removed"].item()) == int(removed.sum())
+    # buckets: record i = doc*bands + band; its bucket representative's doc must be the bucket's min doc
+    rb = as_u64(out["rec_bucket"]).reshape(n, b)
+    bmin = (rb // b).T
+    assert (bmin == mini_expected[f"bucketmin_b{b}_r{r}_K{K}"]).all()
+    assert out["n_collisions"] == 0
+    # edges only connect documents of one component
+    eu, ev = as_u32(out["edge_u"]), as_u32(out["edge_v"])
+    assert (labels[eu] == labels[ev]).all()
+
+
+@pytest.mark.parametrize("key_bits", [1, 4, 10])
+def test_surrogate_collisions_resolved_exactly(engine, mini_docs, mini_expected, key_bits):
+    """truncate the surrogate key so that different tuples share slots: result must not change"""
+    text, offs_d, _, _ = _dev(engine, mini_docs)
+    out = dedup_local(engine, text, offs_d, 128, 13, "char", 9, 13, key_bits=key_bits)
+    assert out["n_collisions"] > 0
+    assert (as_u32(out["labels"]) == mini_expected["labels_b9_r13_K128"]).all()
+
+
+def test_dedup_synthetic_vs_oracle(engine):
+    spec = corpus.CorpusSpec(20000, 300, lang="mixed", dup_frac=0.25, edit_rate=0.01, short_frac=0.01)
+    text, offs = corpus.generate(spec, device=engine.device)
+    for (b, r, K) in [(9, 13, 128), (20, 12, 256)]:
+        out = dedup_local(engine, text, offs, K, 13, "char", b, r)
+        sig = as_u32(out["sig"])
+        exp_sig = RC.signatures(text.cpu().numpy(), offs.cpu().numpy().astype(np.uint64), K)
+        assert (sig == exp_sig).all()
+        exp_labels, _ = RC.cluster(exp_sig, b, r)
+        assert (as_u32(out["labels"]) == exp_labels).all()
+        assert int(out["n_removed"].item()) == int((exp_labels != np.arange(spec.n_docs)).sum()) > 0
+
+
+def test_components_adversarial(engine):
+    """union-find on long chains, stars and random graphs vs the oracle's labels"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 200000
+    chain = np.stack([np.arange(1, 50000), np.arange(0, 49999)], 1)
+    star = np.stack([np.arange(60001, 90000), np.full(29999, 60000)], 1)
+    rnd = rng.integers(100000, n, (80000, 2))
+    edges = np.concatenate([chain[::-1], star, rnd]).astype(np.uint32)
+    edges = edges[rng.permutation(len(edges))]
+    labels = engine.components_init(n)
+    eu, ev = engine.to_device(np.ascontiguousarray(edges[:, 0])), engine.to_device(np.ascontiguousarray(edges[:, 1]))
+    half = len(edges) // 2
+    engine.components_union(labels, eu[:half], ev[:half])
+    engine.components_union(labels, eu[half:], ev[half:])
+    engine.components_finish(labels)
+    exp = R.components_min_label(n, [(int(u), int(v)) for u, v in edges if u != v])
+    assert (as_u32(labels) == exp).all()
+
+
+def test_empty_and_degenerate_inputs(engine):
+    for docs in ([], [""], ["", "", ""], ["x"], ["short", "short"]):
+        text, offs_d, buf, offs = _dev(engine, docs)
+        out = dedup_local(engine, text, offs_d)
+        n = len(docs)
+        sig = as_u32(out["sig"]).reshape(n, 128)
+        assert (sig == 0xFFFFFFFF).all()
+        lab = as_u32(out["labels"])
+        assert (lab == 0).all()          # all-max signatures collide in every band: one component
+        assert int(out["n_removed"].item()) == max(0, n - 1)
+
+
+def test_full_size_properties(engine):
+    """C2-shaped shard (200k docs ~2 KB): size-independent properties instead of a full oracle run:
+    exact copies get identical signatures and one component; K=128 is a prefix of K=256;
+    a sample of documents matches the oracle bit for bit; n_removed = sum(|component|-1)."""
+    spec = corpus.CorpusSpec(200000, 2048, lang="en", dup_frac=0.15, edit_rate=0.0)   # edit_rate 0: exact copies
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    out = dedup_local(engine, text, offs)
+    sig = out["sig"]
+    src = torch.from_numpy(spec.src).to(engine.device)
+    assert torch.equal(sig, sig[src])
+    labels = out["labels"].to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(labels, labels[src])
+    assert bool((labels <= torch.arange(spec.n_docs, device=engine.device)).all())
+    n_comp = int((labels == torch.arange(spec.n_docs, device=engine.device)).sum().item())
+    assert int(out["n_removed"].item()) == spec.n_docs - n_comp
+    assert int(out["n_removed"].item()) >= int(spec.is_dup.sum())
+    s256 = engine.signatures(text, offs, 256)
+    assert torch.equal(s256[:, :128], sig)
+    sample = np.random.Generator(np.random.PCG64(1)).choice(spec.n_docs, 400, replace=False)
+    o = offs.cpu().numpy()
+    th = text.cpu().numpy()
+    docs = [bytes(th[o[i]:o[i + 1]]) for i in sample]
+    buf, so = pack_texts(docs)
+    exp = RC.signatures(buf, so, 128)
+    assert (as_u32(sig[torch.from_numpy(sample).to(engine.device)]) == exp).all()
