@@ -49,8 +49,10 @@ typedef struct mdd_ctx mdd_ctx;
 int mdd_version(void);
 const char* mdd_last_error(void);
 
-/* Context = (device, stream).  `hip_stream` may be NULL (the library creates and owns a
- * stream) or an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+/* Context = (device, stream).  `hip_stream` is the hipStream_t every kernel of this context
+ * is enqueued on, e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's default (null)
+ * stream.  The library never creates a stream of its own, so its kernels are ordered with
+ * the caller's copies and kernels on that stream. */
 int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out);
 int mdd_ctx_destroy(mdd_ctx* ctx);
 int mdd_ctx_sync(mdd_ctx* ctx);

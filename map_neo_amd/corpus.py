@@ -87,12 +87,13 @@ class CorpusSpec:
             # pick an earlier document; squaring the uniform favours few popular sources -> clusters
             u = rng.random(idx.size) ** 2
             s = np.minimum((u * idx).astype(np.int64), idx - 1)
-            s = src[s]                      # sources were assigned in order, so src[s] is final for s < idx
-            # ensure the chain is flattened (source of a dup must be an original)
-            for _ in range(4):
-                s = np.where(is_dup[s], src[s], s)
             src[idx] = s
-            is_dup[idx] = src[idx] != idx
+            while True:                     # pointer jumping: the source of a copy must be an original
+                nxt = src[src]
+                if np.array_equal(nxt, src):
+                    break
+                src = nxt
+            is_dup = src != np.arange(n)
         ntok = ntok[src]                    # near-copies keep the token count of their source
         self.is_zh = self.is_zh[src]
         self.src, self.is_dup, self.ntok = src, is_dup, ntok

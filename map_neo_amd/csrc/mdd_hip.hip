@@ -786,24 +786,15 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     mdd_ctx* c = new mdd_ctx();
     c->device = device;
     c->cus = prop.multiProcessorCount;
-    if (hip_stream) {
-        c->stream = (hipStream_t)hip_stream;
-        c->owns_stream = false;
-    } else {
-        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (se != hipSuccess) {
-            delete c;
-            return fail(MDD_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se));
-        }
-        c->owns_stream = true;
-    }
+    // NULL is HIP's default (null) stream -- the stream torch uses unless told otherwise
+    c->stream = (hipStream_t)hip_stream;
+    c->owns_stream = false;
     *out = c;
     return MDD_OK;
 }
 
 int mdd_ctx_destroy(mdd_ctx* ctx) {
     if (!ctx) return MDD_OK;
-    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return MDD_OK;
 }
@@ -830,10 +821,10 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
     int rc = check_sig_common("mdd_signatures", ctx, text, text_bytes, unit, width);
     if (rc) return rc;
     REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "mdd_signatures: K=%d outside [1,%d]", K, MDD_MAX_PERM);
+    if (n_docs == 0) return MDD_OK;
     REQUIRE(offsets && a && b && sig_out, "mdd_signatures: NULL pointer argument");
     REQUIRE(n_docs <= 0x7FFFFFFFull * WAVES, "mdd_signatures: n_docs=%llu too large for one launch",
             (unsigned long long)n_docs);
-    if (n_docs == 0) return MDD_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     SigArgs A{};
     A.text = text;
@@ -874,7 +865,9 @@ int mdd_shingle_hashes(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, u
 
 int mdd_band_keys(mdd_ctx* ctx, const uint32_t* sig, uint64_t n_docs, int K, int bands, int rows, uint64_t doc_base,
                   int key_bits, uint64_t* key, uint64_t* meta) {
-    REQUIRE(ctx && sig && key && meta, "mdd_band_keys: NULL argument");
+    REQUIRE(ctx != nullptr, "mdd_band_keys: ctx is NULL");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(sig && key && meta, "mdd_band_keys: NULL argument");
     REQUIRE(bands >= 1 && bands <= MDD_MAX_BANDS && rows >= 1 && (int64_t)bands * rows <= K,
             "mdd_band_keys: bands=%d rows=%d do not fit K=%d", bands, rows, K);
     REQUIRE(key_bits >= 1 && key_bits <= 64, "mdd_band_keys: key_bits=%d outside [1,64]", key_bits);
@@ -1023,9 +1016,9 @@ int mdd_valu_calibrate(mdd_ctx* ctx, int iters, double* tops_host) {
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(out);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
     double ops = (double)blocks * 256.0 * (double)iters * 4 * 8 * 2;
     *tops_host = ops / (best * 1e-3) / 1e12;
     return MDD_OK;
