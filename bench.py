@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- MinHash-LSH near-dedup throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (signatures -> band records -> buckets/edges ->
+union-find -> removed mask) over a synthetic corpus already resident in HBM.
+Workload at N=1: BASELINE.json configs[1] ("C2"): 1M synthetic English docs (~2 KB avg),
+char 13-grams, num_perm=128, 9 bands x 13 rows.  For N>1 every rank holds its own C2-sized
+shard (weak scaling) and the band records are exchanged with an RCCL all-to-all.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (sig_kernel, VALU-bound
+integer work: SURVEY.md 8(d)); `cpu_baseline` is the oracle port timed on this host's cores
+(rank 0, N=1 only; bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, K, BANDS, ROWS = 13, 128, 9, 13
+OPS_PER_SHINGLE = lambda k: 958 + 14 * k          # SURVEY.md 8(d) algorithmic int32 ops per shingle
+PEAK_VALU_TOPS = 78.6                             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= FP32 vector FMA rate, MI355X_MICROARCH.md)
+
+
+def _cpu_worker(args):
+    """One shard of the CPU baseline: the reference's per-document loop (ZH-1:23-33 / EN:56-64),
+    restated in oracle/ref_py.py -- MinHash object (and permutation table) rebuilt per doc."""
+    docs, = args
+    from oracle import ref_py as R
+    out = []
+    for t in docs:
+        m = R.MinHash(num_perm=K)                 # regenerates the table, as MinHash(num_perm=128) does
+        for f in R.shingles_char(t, WIDTH):
+            m.update(f)
+        out.append(m.hashvalues)
+    return out
+
+
+def cpu_baseline(n_sample: int, mean_bytes: int, seed: int):
+    """Python port (numpy + hashlib), multiprocessing.Pool over host cores like ZH-1:68-78,
+    on the first n_sample documents of the same synthetic corpus; bucketing + CC included."""
+    import multiprocessing as mp
+
+    import numpy as np
+
+    from map_neo_amd import corpus
+    from oracle import ref_c as RC
+    from oracle import ref_py as R
+    cores = min(16, os.cpu_count() or 1)          # the GPU box gives one GPU a 16-CPU share
+    spec = corpus.CorpusSpec(n_sample, mean_bytes, seed=seed, lang="en")
+    text, offs = corpus.generate(spec)
+    tb = text.numpy().tobytes()
+    o = offs.numpy()
+    docs = [tb[o[i]:o[i + 1]].decode("utf8") for i in range(n_sample)]
+    shards = [(docs[i::cores],) for i in range(cores)]
+    t0 = time.time()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, shards)
+    sig = np.empty((n_sample, K), np.uint32)
+    for i, r in enumerate(res):
+        sig[i::cores] = np.asarray(r, dtype=np.uint64).astype(np.uint32).reshape(-1, K)
+    bk = R.buckets(sig, BANDS, ROWS)              # dict bucketing like ZH-2:19-40
+    edges = set()
+    for members in bk.values():
+        edges.update(R.star_edges(members))
+    labels = R.components_min_label(n_sample, edges)
+    dt = time.time() - t0
+    # optimised single-core C restatement, same sample
+    t1 = time.time()
+    sig_c = RC.signatures(text.numpy(), o.astype(np.uint64), K, WIDTH)
+    RC.cluster(sig_c, BANDS, ROWS)
+    dt_c = time.time() - t1
+    assert (sig_c == sig).all()
+    nbytes = int(o[-1])
+    return {"value": n_sample / dt, "unit": "docs/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sample}-doc corpus from the workload's generator and parameters ({nbytes / 1e6:.1f} MB), python port "
+                      f"(numpy+hashlib, per-doc MinHash like the reference) on {cores} processes, {dt:.1f} s",
+            "gb_per_s": nbytes / dt / 1e9,
+            "c_port_1core_docs_per_s": n_sample / dt_c, "n_removed_sample": int((labels != np.arange(n_sample)).sum())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
+    ap.add_argument("--mean-bytes", type=int, default=2048)
+    ap.add_argument("--cpu-sample-docs", type=int, default=16000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    seed = 20240519 + 2                           # config id 2
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(args.cpu_sample_docs, args.mean_bytes, seed)   # before any GPU init (uses fork)
+
+    import torch
+    import torch.distributed as dist
+
+    from map_neo_amd import corpus
+    from map_neo_amd.dedup import StageTimer, dedup_distributed, dedup_local
+    from map_neo_amd.minhash import Engine
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    eng = Engine(local_rank)
+    dev = eng.device
+
+    n_local = args.docs
+    n_global = n_local * world
+    # one global corpus spec; each rank generates its contiguous shard (near-duplicates cross shards)
+    spec = corpus.CorpusSpec(n_global, args.mean_bytes, seed=seed, lang="en")
+    d0 = rank * n_local
+    t_gen = time.time()
+    texts, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
+    for c0 in range(d0, d0 + n_local, 32768):
+        c1 = min(d0 + n_local, c0 + 32768)
+        t, o = corpus.generate(spec, c0, c1, dev)
+        nb = int(o[-1].item())
+        texts.append(t[:nb])
+        offs.append(o[1:] + base)
+        base += nb
+    text_bytes = base
+    text = torch.zeros(((text_bytes + 3) // 4) * 4 + 4, dtype=torch.uint8, device=dev)
+    torch.cat(texts, out=text[:text_bytes])
+    offsets = torch.cat(offs)
+    del texts, offs
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    lens = offsets[1:] - offsets[:-1]
+    n_shingles = int(torch.clamp(lens - (WIDTH - 1), min=0).sum().item())      # ASCII corpus: code points == bytes
+
+    def step(timer=None):
+        if world == 1:
+            return dedup_local(eng, text, offsets, K, WIDTH, "char", BANDS, ROWS, text_bytes=text_bytes, timer=timer)
+        return dedup_distributed(eng, text, offsets, d0, n_global, K, WIDTH, "char", BANDS, ROWS,
+                                 text_bytes=text_bytes, timer=timer)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    timer = StageTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(timer)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stages = timer.result_ms()
+    n_removed = int(out["n_removed"].item())
+    if world > 1:
+        nr = torch.tensor([n_removed], dtype=torch.int64, device=dev)
+        dist.all_reduce(nr)
+        n_removed = int(nr.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        sig_ms = stages.get("signatures", 0.0) / args.steps       # HIP events on the launch stream, timed region
+        achieved = n_shingles * OPS_PER_SHINGLE(K) / (sig_ms * 1e-3) / 1e12 if sig_ms else None
+        res = {
+            "metric": "docs/sec MinHash-LSH dedup (signatures->bands->buckets->union-find), text resident in HBM",
+            "value": n_global / (dt / args.steps),
+            "unit": "docs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32/u64 integer",
+            "data": "synthetic",
+            "config": {"workload": "C2: %d synthetic English docs per GPU (~%d B avg), char 13-gram shingles, "
+                                   "num_perm=128, 9 bands x 13 rows, seed 1" % (n_local, args.mean_bytes),
+                       "docs_per_gpu": n_local, "global_docs": n_global, "text_bytes_per_gpu": text_bytes,
+                       "shingles_per_gpu": n_shingles, "parallelism": "dp%d" % world},
+            "text_gb_per_s": text_bytes * world / (dt / args.steps) / 1e9,
+            "n_removed": n_removed,
+            "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stages.items()},
+            "corpus_gen_s": t_gen,
+            "roofline": {"bound": "valu", "kernel": "sig_kernel<2,false>", "achieved": achieved, "peak": PEAK_VALU_TOPS,
+                         "unit": "Tops/s (int32 lane-ops)", "frac": (achieved / PEAK_VALU_TOPS) if achieved else None,
+                         "traffic": None, "kernel_ms": sig_ms,
+                         "algorithmic_ops_per_shingle": OPS_PER_SHINGLE(K),
+                         "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz; BASELINE.md's 64-lane figure is 39.3"},
+        }
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,16 +37,41 @@ def _resolve_sig_layout(be, coll_idx, sig, meta, bands, rows):
     return resolve_collisions(coll_idx, meta_h, tuple_of)
 
 
+class StageTimer:
+    """Optional per-stage timing with events on the current stream (bench only)."""
+
+    def __init__(self):
+        self.marks = []
+
+    def mark(self, name: str):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.marks.append((name, ev))
+
+    def result_ms(self) -> dict:
+        torch.cuda.synchronize()
+        out = {}
+        for (_, e0), (name, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
 def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = NUM_PERM, width: int = WIDTH,
                 unit: str = "char", bands: int = BANDS, rows: int = ROWS, seed: int = SEED,
-                text_bytes: Optional[int] = None, key_bits: int = 64, want_buckets: bool = False):
+                text_bytes: Optional[int] = None, key_bits: int = 64, want_buckets: bool = False,
+                timer: Optional[StageTimer] = None):
     """One-GPU path.  Returns a dict of device tensors: sig [n,K], edge_u/edge_v, labels [n]
     (label = smallest doc index of the component), removed [n] uint8, n_removed (device
     int64[1]), n_collisions (host int)."""
     n = offsets.numel() - 1
+    mark = timer.mark if timer is not None else (lambda name: None)
+    mark("start")
     sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
+    mark("signatures")
     key, meta = be.band_keys(sig, bands, rows, 0, key_bits)
+    mark("band_keys")
     eu, ev, coll_idx, rb = be.bucket_edges(key, meta, sig, bands, num_perm, rows, rows, want_buckets)
+    mark("bucket_edges")
     labels = be.components_init(n)
     be.components_union(labels, eu, ev)
     extra = _resolve_sig_layout(be, coll_idx, sig, meta, bands, rows)
@@ -56,6 +81,7 @@ def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = N
         eu, ev = torch.cat([eu, xu]), torch.cat([ev, xv])
     be.components_finish(labels)
     removed, n_removed = be.removed_mask(labels, 0, n)
+    mark("components")
     return {"sig": sig, "key": key, "meta": meta, "edge_u": eu, "edge_v": ev, "labels": labels,
             "removed": removed, "n_removed": n_removed, "n_collisions": int(coll_idx.size),
             "rec_bucket": rb}
@@ -88,15 +114,19 @@ def _all_gather_v(t: torch.Tensor, group=None):
 def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: int, n_global: int,
                       num_perm: int = NUM_PERM, width: int = WIDTH, unit: str = "char", bands: int = BANDS,
                       rows: int = ROWS, seed: int = SEED, text_bytes: Optional[int] = None, key_bits: int = 64,
-                      group=None, timings: Optional[dict] = None):
+                      group=None, timings: Optional[dict] = None, timer: Optional[StageTimer] = None):
     """Multi-GPU path; every rank calls it with its own shard (documents doc_base ..
     doc_base+n_local of n_global).  Returns the same dict as dedup_local; labels cover all
     n_global documents (replicated), removed covers the local shard."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n_local = offsets.numel() - 1
+    mark = timer.mark if timer is not None else (lambda name: None)
+    mark("start")
     sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
+    mark("signatures")
     key, meta = be.band_keys(sig, bands, rows, doc_base, key_bits)
+    mark("band_keys")
     # --- route band records to their owner rank (all-to-all over xGMI)
     tuples_s, meta_s, send_counts = be.route(sig, key, meta, bands, rows, world)
     send_counts = [int(c) for c in send_counts.tolist()]
@@ -106,6 +136,7 @@ def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: i
     recv_counts = [int(c) for c in rc.tolist()]
     tuples_r = _all_to_all_v(tuples_s, send_counts, recv_counts, rows, group)
     meta_r = _all_to_all_v(meta_s, send_counts, recv_counts, 1, group)
+    mark("all_to_all")
     # --- local buckets over the records this rank owns
     key_r = be.packed_keys(tuples_r, meta_r, rows, key_bits)
     eu, ev, coll_idx, _ = be.bucket_edges(key_r, meta_r, tuples_r, 1, rows, 0, rows, False)
@@ -115,13 +146,16 @@ def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: i
         xu, xv = resolve_collisions(coll_idx, meta_h, lambda i: tup_h[i].tobytes())
         if xu.size:
             eu, ev = torch.cat([eu, be.to_device(xu)]), torch.cat([ev, be.to_device(xv)])
+    mark("bucket_edges")
     # --- merge: all-gather every rank's edges, identical union-find everywhere
     eu_all = _all_gather_v(eu, group)
     ev_all = _all_gather_v(ev, group)
+    mark("all_gather")
     labels = be.components_init(n_global)
     be.components_union(labels, eu_all, ev_all)
     be.components_finish(labels)
     removed, n_removed = be.removed_mask(labels, doc_base, n_local)
+    mark("components")
     if timings is not None:
         timings["records_sent"] = int(sum(send_counts))
         timings["records_received"] = int(sum(recv_counts))

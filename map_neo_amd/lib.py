@@ -50,6 +50,9 @@ def load():
             raise MddError(
                 f"{SO_PATH} not found: build it with `make -C map_neo_amd/csrc` "
                 "(or __graft_entry__.build()).  map_neo_amd has no CPU fallback.")
+        # torch ships its own libamdhip64; load it FIRST so that libmdd_hip.so binds to the same
+        # HIP runtime instance torch uses (two runtimes in one process do not share devices/streams)
+        import torch  # noqa: F401
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError if the .so lacks a declared symbol
