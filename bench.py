@@ -111,7 +111,7 @@ def main():
 
     from map_neo_amd import corpus
     from map_neo_amd.dedup import StageTimer, dedup_distributed, dedup_local
-    from map_neo_amd.minhash import Engine
+    from map_neo_amd.minhash import Engine, padded_size
 
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -135,7 +135,7 @@ def main():
         offs.append(o[1:] + base)
         base += nb
     text_bytes = base
-    text = torch.zeros(((text_bytes + 3) // 4) * 4 + 4, dtype=torch.uint8, device=dev)
+    text = torch.zeros(padded_size(text_bytes), dtype=torch.uint8, device=dev)
     torch.cat(texts, out=text[:text_bytes])
     offsets = torch.cat(offs)
     del texts, offs

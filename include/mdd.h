@@ -39,6 +39,7 @@ extern "C" {
 #define MDD_UNIT_CHAR 0 /* shingle unit = Unicode code point (EN:61, ZH-1:27: nltk.ngrams over a str) */
 #define MDD_UNIT_WORD 1 /* shingle unit = space-separated token (BASELINE.json config 1; extension) */
 
+#define MDD_TEXT_PAD 128 /* bytes the text allocation must extend past text_bytes (kernels load unclamped) */
 #define MDD_MAX_PERM 256
 #define MDD_MAX_BANDS 64
 #define MDD_NO_EDGE 0xFFFFFFFFu
@@ -68,8 +69,8 @@ int mdd_make_perms(uint32_t seed, int K, uint64_t* a_host, uint64_t* b_host);
  * shingle (code-point or token windows of `width`, no padding) -> utf-8 bytes -> SHA-1 ->
  * hv = little-endian u32 of digest[0:4] -> for i<K:
  *   sig[i] = min(sig[i], ((a_i*hv + b_i) mod 2^64) mod (2^61-1) & 0xFFFFFFFF), init 0xFFFFFFFF.
- *  text       packed utf-8 of all documents, 4-byte aligned; the allocation must extend to
- *             a multiple of 4 bytes past text_bytes (padding content is ignored)
+ *  text       packed utf-8 of all documents, 4-byte aligned; the allocation must extend
+ *             MDD_TEXT_PAD bytes past text_bytes (padding content is ignored)
  *  offsets    n_docs+1 ascending byte offsets into text (document d = [offsets[d], offsets[d+1]))
  *             each document must be shorter than 4 GiB
  *  a, b       device copies of the permutation table (K entries each)

@@ -124,7 +124,7 @@ def _tokens(spec: CorpusSpec, d0: int, d1: int, device) -> Tuple[torch.Tensor, .
 
 
 def generate(spec: CorpusSpec, d0: int = 0, d1: Optional[int] = None, device="cpu"):
-    """Packed utf-8 text (uint8, padded with >= 4 zero bytes to a multiple of 4) and int64
+    """Packed utf-8 text (uint8, padded with MDD_TEXT_PAD = 128 zero bytes) and int64
     offsets[n+1] for documents [d0, d1) of the corpus."""
     d1 = spec.n_docs if d1 is None else d1
     device = torch.device(device)
@@ -142,7 +142,7 @@ def generate(spec: CorpusSpec, d0: int = 0, d1: Optional[int] = None, device="cp
     doc_bytes.index_add_(0, doc_local, tbytes)
     offsets = torch.zeros(nd + 1, dtype=torch.int64, device=device)
     offsets[1:] = torch.cumsum(doc_bytes, 0)
-    cap = ((total + 3) // 4) * 4 + 4
+    cap = ((total + 3) // 4) * 4 + 128           # MDD_TEXT_PAD
     text = torch.zeros(cap, dtype=torch.uint8, device=device)
     if total:
         tid = torch.repeat_interleave(torch.arange(tok.numel(), device=device), tbytes)
@@ -168,7 +168,7 @@ def generate_chunked(spec: CorpusSpec, device, docs_per_chunk: int = 32768):
         offs.append(o[1:] + base)
         base += nb
     total = base
-    cap = ((total + 3) // 4) * 4 + 4
+    cap = ((total + 3) // 4) * 4 + 128
     text = torch.zeros(cap, dtype=torch.uint8, device=device)
     if texts:
         torch.cat(texts, out=text[:total])

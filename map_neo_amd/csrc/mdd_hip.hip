@@ -108,22 +108,24 @@ __device__ __forceinline__ void sha1_compress(uint32_t (&st)[5], uint32_t (&w)[1
     uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4];
 #pragma unroll
     for (int t = 0; t < 80; t++) {
+        // v_bitop3_b32 (gfx950): any 3-input boolean in one instruction.  0x96 = x^y^z,
+        // 0xCA = Ch, 0xE8 = Maj.  Measured: -14 % SHA-1 time vs the two-xor forms.
         if (t >= 16) {
-            uint32_t x = w[(t - 3) & 15] ^ w[(t - 8) & 15] ^ w[(t - 14) & 15] ^ w[t & 15];
+            uint32_t x = __builtin_amdgcn_bitop3_b32(w[(t - 3) & 15], w[(t - 8) & 15], w[(t - 14) & 15], 0x96) ^ w[t & 15];
             w[t & 15] = rol(x, 1);
         }
         uint32_t f, k;
         if (t < 20) {
-            f = d ^ (b & (c ^ d));
+            f = __builtin_amdgcn_bitop3_b32(b, c, d, 0xCA);
             k = 0x5A827999u;
         } else if (t < 40) {
-            f = b ^ c ^ d;
+            f = __builtin_amdgcn_bitop3_b32(b, c, d, 0x96);
             k = 0x6ED9EBA1u;
         } else if (t < 60) {
-            f = (b & c) | (d & (b ^ c));
+            f = __builtin_amdgcn_bitop3_b32(b, c, d, 0xE8);
             k = 0x8F1BBCDCu;
         } else {
-            f = b ^ c ^ d;
+            f = __builtin_amdgcn_bitop3_b32(b, c, d, 0x96);
             k = 0xCA62C1D6u;
         }
         uint32_t tmp = rol(a, 5) + f + e + k + w[t & 15];
@@ -140,14 +142,15 @@ __device__ __forceinline__ void sha1_compress(uint32_t (&st)[5], uint32_t (&w)[1
     st[4] += e;
 }
 
+// Text access: `docw` is the (wave-uniform) aligned dword that contains the first byte of the
+// document; a shingle is addressed by p = byte offset from docw (32 bit).  Loads run up to
+// 80 bytes past the shingle start and are NOT clamped: the caller's allocation extends
+// MDD_TEXT_PAD bytes past text_bytes (include/mdd.h).
 struct TextView {
-    const uint32_t* t32;  // 4-byte aligned base of the packed text
-    uint64_t last;        // index of the last dword that may be loaded
+    const uint32_t* docw;
 };
 
-__device__ __forceinline__ uint32_t ld_dword(const TextView& tv, uint64_t idx) {
-    return tv.t32[idx < tv.last ? idx : tv.last];
-}
+__device__ __forceinline__ uint32_t ld_dword(const TextView& tv, uint32_t idx) { return tv.docw[idx]; }
 
 // Big-endian message word covering message bytes [pos, pos+4) of a message of L bytes,
 // rem = L - pos: data bytes, then the 0x80 pad, then zeros.  (lo,hi) are the two aligned
@@ -162,12 +165,15 @@ __device__ __forceinline__ uint32_t msg_word(uint32_t lo, uint32_t hi, uint32_t 
     return (be & keep) | (0x80000000u >> (8 * rem));
 }
 
-// datasketch sha1_hash32 of the L-byte shingle at absolute byte offset s, single block.
+// datasketch sha1_hash32 of the L-byte shingle at byte offset p from tv.docw, single block.
 // NW = number of leading message words that can be non-zero; requires L <= 4*NW - 1.
-template <int NW>
-__device__ __forceinline__ uint32_t hash_single(const TextView& tv, uint64_t s, uint32_t L) {
-    uint64_t base = s >> 2;
-    uint32_t sh = (uint32_t)s & 3u;
+// FIXEDL > 0: every lane's L equals FIXEDL (pure-ASCII document, L = width): the padding
+// masks fold at compile time.
+template <int NW, int FIXEDL>
+__device__ __forceinline__ uint32_t hash_single(const TextView& tv, uint32_t p, uint32_t L) {
+    if (FIXEDL > 0) L = FIXEDL;
+    uint32_t base = p >> 2;
+    uint32_t sh = p & 3u;
     uint32_t dw[NW + 1];
 #pragma unroll
     for (int k = 0; k <= NW; k++) dw[k] = ld_dword(tv, base + k);
@@ -183,18 +189,21 @@ __device__ __forceinline__ uint32_t hash_single(const TextView& tv, uint64_t s, 
 }
 
 // any length (multi-block); lanes may run different block counts
-__device__ __noinline__ uint32_t hash_multi(const TextView& tv, uint64_t s, uint32_t L) {
-    uint64_t base = s >> 2;
-    uint32_t sh = (uint32_t)s & 3u;
+__device__ __noinline__ uint32_t hash_multi(const uint32_t* docw, uint32_t p, uint32_t L) {
+    uint32_t base = p >> 2;
+    uint32_t sh = p & 3u;
     uint32_t nblk = (L + 8u) / 64u + 1u;
     uint32_t st[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
     for (uint32_t bi = 0; bi < nblk; bi++) {
         uint32_t w[16];
-        uint32_t lo = ld_dword(tv, base + 16ull * bi);
+        uint32_t lo = docw[base + 16u * bi];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            uint32_t hi = ld_dword(tv, base + 16ull * bi + k + 1);
-            w[k] = msg_word(lo, hi, sh, (int)L - (int)(64u * bi) - 4 * k);
+            // a word that lies wholly behind the padding is zero whatever is loaded; do not
+            // load far past the shingle (keeps every access within MDD_TEXT_PAD of the text)
+            int rem = (int)L - (int)(64u * bi) - 4 * k;
+            uint32_t hi = rem > -4 ? docw[base + 16u * bi + k + 1] : 0u;
+            w[k] = msg_word(lo, hi, sh, rem);
             lo = hi;
         }
         if (bi == nblk - 1) w[15] = L * 8u;  // L < 2^29 is enforced on the host
@@ -204,11 +213,12 @@ __device__ __noinline__ uint32_t hash_multi(const TextView& tv, uint64_t s, uint
 }
 
 // wave-uniform dispatch on the longest shingle of the round
-__device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint64_t s, uint32_t L, uint32_t Lmax) {
-    if (Lmax <= 15u) return hash_single<4>(tv, s, L);
-    if (Lmax <= 39u) return hash_single<10>(tv, s, L);
-    if (Lmax <= 55u) return hash_single<14>(tv, s, L);
-    return hash_multi(tv, s, L);
+__device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint32_t p, uint32_t L, uint32_t Lmax, bool fixed13) {
+    if (fixed13) return hash_single<4, 13>(tv, p, L);
+    if (Lmax <= 15u) return hash_single<4, 0>(tv, p, L);
+    if (Lmax <= 39u) return hash_single<10, 0>(tv, p, L);
+    if (Lmax <= 55u) return hash_single<14, 0>(tv, p, L);
+    return hash_multi(tv.docw, p, L);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -234,7 +244,10 @@ __device__ __forceinline__ void wave_sync() {  // order this wave's LDS traffic 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int WAVES = 4;         // waves (= documents in flight) per workgroup
+#ifndef MDD_WAVES
+#define MDD_WAVES 1
+#endif
+constexpr int WAVES = MDD_WAVES;  // waves (= documents in flight) per workgroup; 1 frees a wave slot as soon as its document ends
 constexpr int RING = 512;        // code-point / token boundary ring per wave (entries)
 constexpr uint32_t FAST_GUARD = 8u;
 
@@ -265,8 +278,11 @@ struct SigArgs {
     uint64_t* dump_n;
 };
 
+#ifndef MDD_WPE
+#define MDD_WPE 3
+#endif
 template <int KPL, bool DUMP>
-__global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(MDD_WPE, 8))) sig_kernel(SigArgs A) {
     __shared__ WaveLds lds_all[WAVES];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
@@ -288,8 +304,8 @@ __global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
     const uint32_t width = (uint32_t)A.width;
     const uint8_t* text = A.text;
     TextView tv;
-    tv.t32 = reinterpret_cast<const uint32_t*>(text);
-    tv.last = A.text_bytes ? ((A.text_bytes - 1) >> 2) : 0;
+    tv.docw = reinterpret_cast<const uint32_t*>(text) + (beg >> 2);
+    const uint32_t boff = (uint32_t)beg & 3u;  // byte offset of the document inside docw[0]
 
     // ---- permutation constants: lane owns perms q*64 + lane
     uint32_t alo[KPL], ahi[KPL], blo[KPL], bhi[KPL];
@@ -314,8 +330,8 @@ __global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
     if (unit == MDD_UNIT_CHAR) {
         uint32_t acc = 0;
         if (len) {
-            uint64_t d0 = beg >> 2, d1 = (end - 1) >> 2;  // dwords touching the doc (may include neighbours: conservative)
-            for (uint64_t i = d0 + lane; i <= d1; i += 64) acc |= tv.t32[i];
+            uint32_t d1 = (boff + len - 1u) >> 2;  // dwords touching the doc (may include neighbours: conservative)
+            for (uint32_t i = lane; i <= d1; i += 64) acc |= tv.docw[i];
         }
         ascii = __ballot((acc & 0x80808080u) != 0u) == 0ull;
     }
@@ -337,14 +353,14 @@ __global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
 
         for (;;) {
             uint32_t nvalid;
-            uint64_t s = 0;
+            uint32_t s = 0;  // byte offset of the lane's shingle from tv.docw
             uint32_t L = 0;
             if (ascii) {
                 uint32_t rest = ascii_total - n_done;
                 nvalid = rest < 64u ? rest : 64u;
                 if (nvalid == 0) break;
                 uint32_t j = n_done + (lane < nvalid ? lane : 0u);
-                s = beg + j;
+                s = boff + j;
                 L = width;
             } else {
                 // ---- fill the boundary ring until a full round is available or the doc ends
@@ -412,12 +428,16 @@ __global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
                 uint32_t sb = lds.ringS[j & (RING - 1)];
                 uint32_t eb = unit == MDD_UNIT_CHAR ? lds.ringS[(j + look) & (RING - 1)]
                                                     : lds.ringE[(j + look) & (RING - 1)];
-                s = beg + sb;
+                s = boff + sb;
                 L = eb - sb;
             }
 
-            uint32_t Lmax = uni(wave_max(L));
-            uint32_t h = hash_any(tv, s, L, Lmax);
+#ifdef MDD_DBG_NOSHA   // development ablation only (tools/sig_bench.hip); never defined in the library build
+            uint32_t h = s * 2654435761u + L;
+#else
+            uint32_t Lmax = ascii ? width : uni(wave_max(L));
+            uint32_t h = hash_any(tv, s, L, Lmax, ascii && width == 13u);
+#endif
 
             if (DUMP) {
                 uint64_t o = (uint64_t)n_done + lane;
@@ -427,9 +447,18 @@ __global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
                 wave_sync();
                 lds.hbuf[lane] = h;
                 wave_sync();
-                const uint32_t n4 = (nvalid + 3u) >> 2;
+#ifdef MDD_DBG_PERM1
+                const uint32_t n4 = 1;
+#else
+                const uint32_t n4 = uni((nvalid + 3u) >> 2);
+#endif
                 const uint4* hb4 = reinterpret_cast<const uint4*>(lds.hbuf);
+#ifdef MDD_DBG_NOPERM
+                m[0] ^= hb4[lane & 15].x;
+                if (false) {
+#else
                 if (!exact) {
+#endif
                     // fast form: t' = a*h + (b+1) mod 2^64 ; s = lo32(t') + (t' >> 61).
                     // If s > 8 then s - 1 is exactly ((a*h+b) mod 2^64) mod (2^61-1) & 0xFFFFFFFF
                     // (proof in DESIGN.md); a minimum <= 8 sends the document to the exact pass.
@@ -442,6 +471,8 @@ __global__ void __launch_bounds__(64 * WAVES) sig_kernel(SigArgs A) {
                             for (int q = 0; q < KPL; q++) {
                                 uint64_t b1 = (((uint64_t)bhi[q] << 32) | blo[q]) + 1ull;
                                 uint64_t t = (uint64_t)alo[q] * hh[e] + b1;
+                                // hipcc fuses this into a second v_mad_u64_u32; a hand-placed
+                                // v_mul_lo_u32 + v_add_u32 measured 7 % slower
                                 uint32_t thi = (uint32_t)(t >> 32) + ahi[q] * hh[e];
                                 uint32_t sv = (uint32_t)t + (thi >> 29);
                                 m[q] = sv < m[q] ? sv : m[q];

@@ -82,6 +82,17 @@ KERNEL32(pk_add_u16,   "v_pk_add_u16 %0, %0, %1")
 KERNEL32(add_u16,      "v_add_u16 %0, %0, %1")
 KERNEL32(sad_u32,      "v_sad_u32 %0, %0, %1, %2")
 KERNEL32(mov_dpp,      "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
+KERNEL32(bitop3_b32,   "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+KERNEL32(add3_sgpr,    "v_add3_u32 %0, %0, %1, s20")
+KERNEL32(xad_sgpr,     "v_xad_u32 %0, %0, %1, s20")
+KERNEL32(add_lit,      "v_add_u32 %0, 0x5A827999, %0")
+KERNEL32(add_sgpr,     "v_add_u32 %0, s20, %0")
+KERNEL32(alignbit_2r,  "v_alignbit_b32 %0, %0, %1, 27")
+KERNEL32(mov_b32,      "v_mov_b32 %0, %1")
+KERNEL32(not_b32,      "v_not_b32 %0, %0")
+KERNEL32(mix_xor_align, "v_xor_b32 %0, %0, %1\n v_alignbit_b32 %0, %0, %0, 27")
+KERNEL32(mix_xor_xor_align, "v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %2\n v_alignbit_b32 %0, %0, %0, 27")
+KERNEL32(mix_add_add3, "v_add_u32 %0, %0, %1\n v_add3_u32 %0, %0, %1, %2")
 KERNEL64(mad_u64_u32,  "v_mad_u64_u32 %0, vcc, %1, %2, %0")
 KERNEL64(fma_f64,      "v_fma_f64 %0, %0, %0, %0")
 KERNEL64(add_f64,      "v_add_f64 %0, %0, %0")
@@ -95,6 +106,8 @@ static Entry entries[] = {
     E(xad_u32), E(and_or_b32), E(perm_b32), E(min_u32), E(min3_u32), E(max3_u32), E(mul_lo_u32),
     E(mul_hi_u32), E(mul_u32_u24), E(mad_u32_u24), E(add_co_u32), E(cndmask_b32), E(fma_f32),
     E(and_b32), E(or_b32), E(sub_u32), E(lshlrev_b32), E(max_u32), E(add_u32_e64), E(xor_e64), E(min_u32_e64), E(bfe_u32), E(or3_b32), E(cmp_cnd), E(pk_add_u16), E(add_u16), E(sad_u32), E(mov_dpp),
+    E(bitop3_b32), E(add3_sgpr), E(xad_sgpr), E(add_lit), E(add_sgpr), E(alignbit_2r), E(mov_b32), E(not_b32),
+    E(mix_xor_align), E(mix_xor_xor_align), E(mix_add_add3),
     E(mad_u64_u32), E(fma_f64), E(add_f64), E(lshlrev_b64),
 };
 

@@ -28,6 +28,14 @@ NUM_PERM = 128
 SEED = 1
 
 
+TEXT_PAD = 128      # MDD_TEXT_PAD (include/mdd.h)
+
+
+def padded_size(text_bytes: int) -> int:
+    """Capacity a text buffer needs for `text_bytes` of content."""
+    return ((int(text_bytes) + 3) // 4) * 4 + TEXT_PAD
+
+
 def as_u32(t: torch.Tensor) -> np.ndarray:
     return t.detach().cpu().numpy().view(np.uint32)
 
@@ -37,7 +45,7 @@ def as_u64(t: torch.Tensor) -> np.ndarray:
 
 
 def pack_texts(texts: Iterable) -> Tuple[np.ndarray, np.ndarray]:
-    """str/bytes documents -> (uint8 text padded to a multiple of 4 + 4 bytes, uint64 offsets[n+1]).
+    """str/bytes documents -> (uint8 text + TEXT_PAD zero bytes, uint64 offsets[n+1]).
     A str that cannot be utf-8 encoded raises (the reference skips such docs: ZH-1:52-54;
     callers that want skip-and-keep semantics filter before packing, as the CLI drivers do)."""
     enc = [t.encode("utf8") if isinstance(t, str) else bytes(t) for t in texts]
@@ -45,7 +53,7 @@ def pack_texts(texts: Iterable) -> Tuple[np.ndarray, np.ndarray]:
     if enc:
         offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
     total = int(offs[-1])
-    buf = np.zeros(((total + 3) // 4) * 4 + 4, dtype=np.uint8)
+    buf = np.zeros(padded_size(total), dtype=np.uint8)
     buf[:total] = np.frombuffer(b"".join(enc), dtype=np.uint8)
     return buf, offs
 
@@ -119,15 +127,15 @@ class Engine:
                    width: int = WIDTH, unit: str = "char", seed: int = SEED,
                    perms: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                    text_bytes: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """text: uint8 device tensor (capacity a multiple of 4 beyond the last byte used);
+        """text: uint8 device tensor of capacity >= padded_size(text_bytes);
         offsets: int64 device tensor [n+1].  Returns int32 tensor [n, K] holding u32 bits."""
         assert text.dtype == torch.uint8 and offsets.dtype == torch.int64
         n = offsets.numel() - 1
         if text_bytes is None:
             text_bytes = int(offsets[-1].item()) if n >= 0 and offsets.numel() else 0
         cap = text.numel()
-        if ((int(text_bytes) + 3) // 4) * 4 > cap:
-            raise _lib.MddError("text tensor must extend to a multiple of 4 bytes past text_bytes")
+        if int(text_bytes) + TEXT_PAD > cap:
+            raise _lib.MddError(f"text tensor must extend {TEXT_PAD} bytes past text_bytes (minhash.padded_size)")
         a, b = perms if perms is not None else self.perms(seed, num_perm)
         sig = out if out is not None else torch.empty((n, num_perm), dtype=torch.int32, device=self.device)
         _lib.check(self.L.mdd_signatures(self.ctx, _ptr(text), int(text_bytes), _ptr(offsets), n,
