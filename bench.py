@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--mean-bytes", type=int, default=2048)
     ap.add_argument("--cpu-sample-docs", type=int, default=16000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="use the multi-GPU path (RCCL all-to-all / all-gather) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,8 +116,12 @@ def main():
     from map_neo_amd.minhash import Engine, padded_size
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank)
     dev = eng.device
@@ -145,13 +151,13 @@ def main():
     n_shingles = int(torch.clamp(lens - (WIDTH - 1), min=0).sum().item())      # ASCII corpus: code points == bytes
 
     def step(timer=None):
-        if world == 1:
+        if not use_dist:
             return dedup_local(eng, text, offsets, K, WIDTH, "char", BANDS, ROWS, text_bytes=text_bytes, timer=timer)
         return dedup_distributed(eng, text, offsets, d0, n_global, K, WIDTH, "char", BANDS, ROWS,
                                  text_bytes=text_bytes, timer=timer)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +202,8 @@ def main():
             "config": {"workload": "C2: %d synthetic English docs per GPU (~%d B avg), char 13-gram shingles, "
                                    "num_perm=128, 9 bands x 13 rows, seed 1" % (n_local, args.mean_bytes),
                        "docs_per_gpu": n_local, "global_docs": n_global, "text_bytes_per_gpu": text_bytes,
-                       "shingles_per_gpu": n_shingles, "parallelism": "dp%d" % world},
+                       "shingles_per_gpu": n_shingles, "parallelism": "dp%d" % world,
+                       "path": "distributed (RCCL all-to-all + all-gather)" if use_dist else "single-GPU"},
             "text_gb_per_s": text_bytes * world / (dt / args.steps) / 1e9,
             "n_removed": n_removed,
             "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stages.items()},
@@ -210,7 +217,7 @@ def main():
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -205,3 +205,41 @@ def test_full_size_properties(engine):
     buf, so = pack_texts(docs)
     exp = RC.signatures(buf, so, 128)
     assert (as_u32(sig[torch.from_numpy(sample).to(engine.device)]) == exp).all()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_routed_packed_path(engine, mini_docs, mini_expected, world):
+    """multi-GPU data path on one GPU: route band records to `world` owners (mdd_route_count /
+    mdd_route_pack), bucket each owner's PACKED records separately (mdd_packed_keys +
+    mdd_bucket_edges), union all edges: labels must equal the one-GPU result."""
+    text, offs_d, _, _ = _dev(engine, mini_docs)
+    n = len(mini_docs)
+    bands, rows, K = 9, 13, 128
+    sig = engine.signatures(text, offs_d, K)
+    key, meta = engine.band_keys(sig, bands, rows, 0)
+    tuples, meta_s, counts = engine.route(sig, key, meta, bands, rows, world)
+    counts = counts.tolist()
+    assert sum(counts) == n * bands
+    # every record lands in the segment of rank (key >> 32) % world, with its own tuple
+    kh = as_u64(key)
+    dest = ((kh >> np.uint64(32)) % np.uint64(world)).astype(np.int64)
+    assert np.bincount(dest, minlength=world).tolist() == counts
+    sig_h = as_u32(sig)
+    tup_h = as_u32(tuples).reshape(-1, rows)
+    meta_h = as_u64(meta_s)
+    for i in range(0, n * bands, 7):
+        d, j = int(meta_h[i] & np.uint64(0xFFFFFFFF)), int(meta_h[i] >> np.uint64(56))
+        assert (tup_h[i] == sig_h[d, j * rows:(j + 1) * rows]).all()
+    labels = engine.components_init(n)
+    start = 0
+    for r in range(world):
+        c = counts[r]
+        t_r = tuples[start * rows:(start + c) * rows]
+        m_r = meta_s[start:start + c]
+        k_r = engine.packed_keys(t_r, m_r, rows)
+        eu, ev, coll, _ = engine.bucket_edges(k_r, m_r, t_r, 1, rows, 0, rows)
+        assert coll.size == 0
+        engine.components_union(labels, eu, ev)
+        start += c
+    engine.components_finish(labels)
+    assert (as_u32(labels) == mini_expected["labels_b9_r13_K128"]).all()
