@@ -1,0 +1,76 @@
+"""CPU suite: host logic of the drop-in commands -- flags match the reference's scripts,
+text normalisation matches the oracle, ZH-4 / ZH-5 bookkeeping (no GPU involved)."""
+import os
+import pickle
+
+import pytest
+
+from map_neo_amd import hostio
+from map_neo_amd.cli import (generate_connected_components, generate_dup_line_id_for_each_file, generate_dup_pairs,
+                             generate_minhash, minhashLsh, remove_dup)
+from oracle import ref_py as R
+
+
+def _flags(parser):
+    return {a.option_strings[0]: a.default for a in parser._actions if a.option_strings and a.option_strings[0] != "-h"}
+
+
+def test_en_flags_match_reference():
+    f = _flags(minhashLsh.build_parser())
+    # EN:11-16
+    for name in ("--input_dir", "--inter_dir", "--output_dir", "--content_field_name"):
+        assert name in f
+    assert f["--content_field_name"] == "raw_content"
+    # reference constants EN:17-20 are the defaults of the extension flags
+    assert (f["--width"], f["--bands"], f["--rows"], f["--num_perm"], f["--seed"]) == (13, 9, 13, 128, 1)
+
+
+def test_zh_flags_match_reference():
+    f = _flags(generate_minhash.build_parser())
+    assert f["--workers"] == 42 and f["--content_field_name"] == "text"          # ZH-1:82-85
+    assert {"--input_dir", "--output_dir"} <= set(f)
+    assert {"--input_dir", "--output_dir"} <= set(_flags(generate_dup_pairs.build_parser()))               # ZH-2:53-54
+    f3 = _flags(generate_connected_components.build_parser())
+    assert {"--input_dir", "--output_file", "--num_workers"} <= set(f3) and f3["--num_workers"] == 90      # ZH-3:65-67
+    assert {"--input_file", "--output_dir"} <= set(_flags(generate_dup_line_id_for_each_file.build_parser()))  # ZH-4:36-37
+    assert {"--input_dir", "--output_dir", "--dup_line_id_dir", "--workers"} <= set(_flags(remove_dup.build_parser()))
+
+
+@pytest.mark.parametrize("text", ["  Hello,   World!\n\tFoo-bar  ", "ＡＢＣ　ｄｅｆ", "école d'été — «test»", "", " \n ",
+                                  "MiXeD CaSe: 123,456.78 (ok)? [yes]"])
+def test_normalize_matches_oracle(text):
+    assert hostio.normalize_text(text) == R.normalize_text(text)
+
+
+def test_zh4_zh5_host_logic(tmp_path):
+    """components -> per-file line-id sets -> filtered files; files without duplicates pass through"""
+    inp, dup, out = tmp_path / "in", tmp_path / "dup", tmp_path / "out"
+    inp.mkdir()
+    (inp / "a.jsonl").write_bytes(b'{"text": "l0"}\n{"text": "l1"}\n{"text": "l2"}\n')
+    (inp / "b.jsonl").write_bytes(b'{"text": "m0"}\n{"text": "m1"}\n')
+    (inp / "c.jsonl").write_bytes(b'{"text": "n0"}\n')
+    comps = [[0, 1, 3], [2, 4]]
+    mapper = {0: "a.jsonl@0", 1: "a.jsonl@2", 2: "a.jsonl@1", 3: "b.jsonl@1", 4: "b.jsonl@0"}
+    cc = tmp_path / "cc.pkl"
+    with open(cc, "wb") as f:
+        pickle.dump((comps, 2, mapper), f)
+    n = generate_dup_line_id_for_each_file.generate_duplicates(
+        generate_dup_line_id_for_each_file.build_parser().parse_args(["--input_file", str(cc), "--output_dir", str(dup)]))
+    assert n == 3
+    assert pickle.load(open(dup / "a.jsonl.pkl", "rb")) == {2}
+    assert pickle.load(open(dup / "b.jsonl.pkl", "rb")) == {0, 1}
+    assert not os.path.exists(dup / "c.jsonl.pkl")
+    remove_dup.main(["--input_dir", str(inp), "--output_dir", str(out), "--dup_line_id_dir", str(dup), "--workers", "2"])
+    assert (out / "a.jsonl").read_bytes() == b'{"text": "l0"}\n{"text": "l1"}\n'
+    assert (out / "b.jsonl").read_bytes() == b""
+    assert (out / "c.jsonl").read_bytes() == b'{"text": "n0"}\n'          # no .pkl: copied unchanged
+
+
+def test_band_key_roundtrip():
+    import numpy as np
+    from map_neo_amd.cli import zh_common as Z
+    sig = R.signatures(["the quick brown fox jumps over the lazy dog", "too short"], 128)
+    for band in range(9):
+        keys = Z.band_key_bytes(sig, band, 13)
+        assert keys[0] == R.band_keys(sig[0].astype(np.uint64), 9, 13)[band]      # == _H(...) of ZH-1:32
+        assert (Z.key_bytes_to_tuples(keys, 13) == sig[:, band * 13:(band + 1) * 13]).all()

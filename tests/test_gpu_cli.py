@@ -1,0 +1,111 @@
+"""GPU suite: the command-line drop-ins end to end against the oracle."""
+import gzip
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from map_neo_amd.cli import (generate_connected_components, generate_dup_line_id_for_each_file, generate_dup_pairs,
+                             generate_minhash, minhashLsh, remove_dup, zh_dedup)
+from oracle import ref_py as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _en_rows(mini_docs):
+    rng = np.random.Generator(np.random.PCG64(21))
+    rows = []
+    for i, d in enumerate(mini_docs):
+        # RedPajama-style string ids whose order differs from file order
+        rows.append({"doc_id": f"shard/{int(rng.integers(0, 5))}/{(i * 7919) % 1000:05d}", "raw_content": "  " + d.upper() + "!! ",
+                     "meta": {"i": i}})
+    rows.append({"doc_id": "shard/9/null", "raw_content": None, "meta": {"i": -1}})
+    return rows
+
+
+def test_en_cli_end_to_end(tmp_path, mini_docs, capsys):
+    rows = _en_rows(mini_docs)
+    inp = tmp_path / "in"
+    inp.mkdir()
+    with open(inp / "part-0.json", "w", encoding="utf8") as f:
+        for r in rows[:120]:
+            f.write(json.dumps(r, ensure_ascii=False) + "\n")
+    with gzip.open(inp / "part-1.json.gz", "wt", encoding="utf8") as f:
+        for r in rows[120:]:
+            f.write(json.dumps(r, ensure_ascii=False) + "\n")
+    minhashLsh.main(["--input_dir", str(inp), "--inter_dir", str(tmp_path / "inter"), "--output_dir", str(tmp_path / "out")])
+    # oracle: EN:119-150 on the same rows
+    cand = [r for r in rows if r["raw_content"] is not None]
+    cand.sort(key=lambda r: r["doc_id"])
+    texts = [R.normalize_text(r["raw_content"]) for r in cand]
+    exp = R.dedup(texts)
+    ids = [r["doc_id"] for r in cand]
+    exp_removed = {ids[k] for k in np.flatnonzero(exp["removed"])}
+    # literal star loop (EN:138-145) gives the same remove_list
+    star = R.large_star_small_star(R.generate_edges(m)[i] for m in exp["buckets"].values() for i in range(len(m) - 1))
+    assert {ids[u] for u, _ in star} == exp_removed
+    out_rows = [json.loads(l) for l in gzip.open(tmp_path / "out" / "part-00000.json.gz", "rt", encoding="utf8")]
+    assert {r["doc_id"] for r in out_rows} == {r["doc_id"] for r in rows} - exp_removed
+    assert all("meta" in r for r in out_rows)                              # all original columns survive
+    assert any(r["raw_content"] is None for r in out_rows)                 # null content is always kept
+    assert f"the number of doc need to be remove is  {len(exp_removed)}" in capsys.readouterr().out
+    sig = np.load(tmp_path / "inter" / "signatures.npy")
+    assert json.load(open(tmp_path / "inter" / "doc_ids.json")) == ids
+    assert (sig == exp["signatures"]).all()
+
+
+def _zh_files(tmp_path, mini_docs):
+    inp = tmp_path / "zh_in"
+    inp.mkdir()
+    files = {"f_a.jsonl": mini_docs[:70], "f_b.jsonl": mini_docs[70:150], "f_c.jsonl": mini_docs[150:]}
+    for name, docs in files.items():
+        with open(inp / name, "w", encoding="utf8") as f:
+            for i, d in enumerate(docs):
+                if name == "f_b.jsonl" and i == 5:
+                    f.write("{broken json\n")                              # skipped line: never removed (ZH-1:52-54)
+                f.write(json.dumps({"text": d, "k": i}, ensure_ascii=False) + "\n")
+    return inp, files
+
+
+def test_zh_five_steps_and_fused(tmp_path, mini_docs):
+    inp, files = _zh_files(tmp_path, mini_docs)
+    M, P, C, D, O = (tmp_path / x for x in ("mh", "pairs", "cc.pkl", "dupids", "out"))
+    generate_minhash.main(["--input_dir", str(inp), "--output_dir", str(M), "--workers", "2"])
+    # artifact format: <M>/<band>/<file>.gz = pickle list of {'doc_id','hash'} with 104-byte keys == oracle _H
+    recs = pickle.load(open(M / "3" / "f_a.jsonl.gz", "rb"))
+    assert recs[13]["doc_id"] == "f_a.jsonl@13" and len(recs[13]["hash"]) == 104
+    assert recs[13]["hash"] == R.band_keys(R.signature(mini_docs[13]), 9, 13)[3]
+    generate_dup_pairs.main(["--input_dir", str(M), "--output_dir", str(P)])
+    assert sorted(os.listdir(P)) == [f"dup_paris_{b}.txt" for b in range(9)]
+    generate_connected_components.main(["--input_dir", str(P), "--output_file", str(C)])
+    generate_dup_line_id_for_each_file.main(["--input_file", str(C), "--output_dir", str(D)])
+    remove_dup.main(["--input_dir", str(inp), "--output_dir", str(O), "--dup_line_id_dir", str(D), "--workers", "2"])
+    # oracle: ids in (file, line) order; keep the smallest member of every component
+    ids, texts = [], []
+    for name in sorted(files):
+        for idx, line in enumerate(open(inp / name, encoding="utf8")):
+            try:
+                texts.append(json.loads(line)["text"])
+                ids.append((name, idx))
+            except Exception:
+                pass
+    exp = R.dedup(texts, edge_shape="star")
+    drop = {}
+    for k in np.flatnonzero(exp["removed"]):
+        drop.setdefault(ids[k][0], set()).add(ids[k][1])
+    for name in files:
+        want = b"".join(l for i, l in enumerate(open(inp / name, "rb")) if i not in drop.get(name, set()))
+        assert (O / name).read_bytes() == want, name
+        if name in drop:
+            assert pickle.load(open(D / (name + ".pkl"), "rb")) == drop[name]
+    comps, n_comp, mapper = pickle.load(open(C, "rb"))
+    assert n_comp == len(comps) == len({int(l) for l in exp["labels"][exp["removed"]]})
+    # fused command gives byte-identical outputs
+    O2 = tmp_path / "out_fused"
+    zh_dedup.main(["--input_dir", str(inp), "--output_dir", str(O2), "--report", str(tmp_path / "rep.json")])
+    for name in files:
+        assert (O2 / name).read_bytes() == (O / name).read_bytes()
+    rep = json.load(open(tmp_path / "rep.json"))
+    assert len(rep["removed"]) == int(exp["removed"].sum())
