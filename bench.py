@@ -26,7 +26,12 @@ sys.path.insert(0, ROOT)
 
 WIDTH, K, BANDS, ROWS = 13, 128, 9, 13
 OPS_PER_SHINGLE = lambda k: 958 + 14 * k          # SURVEY.md 8(d) algorithmic int32 ops per shingle
-PEAK_VALU_TOPS = 78.6                             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= FP32 vector FMA rate, MI355X_MICROARCH.md)
+PEAK_VALU_TOPS = 78.6                             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: one simple int32 op per lane per issue slot
+#                                                   (= half of the guide's 157.3 TFLOPS FP32 vector peak, which counts FMA as 2)
+# Minimum VALU issue time of the shipped instruction stream, in 2-cycle issue slots per
+# shingle (DESIGN.md "Cost model"): SHA-1 single block + message assembly, and per
+# permutation 2 x v_mad_u64_u32 (2.25 each) + v_mov + v_lshrrev + v_add + half a v_min3.
+ISSUE_SLOTS_PER_SHINGLE = lambda k: 1150 + 8.5 * k
 
 
 def _cpu_worker(args):
@@ -212,7 +217,12 @@ def main():
                          "unit": "Tops/s (int32 lane-ops)", "frac": (achieved / PEAK_VALU_TOPS) if achieved else None,
                          "traffic": None, "kernel_ms": sig_ms,
                          "algorithmic_ops_per_shingle": OPS_PER_SHINGLE(K),
-                         "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz; BASELINE.md's 64-lane figure is 39.3"},
+                         "issue_slot_utilisation": (n_shingles * ISSUE_SLOTS_PER_SHINGLE(K) / 78.6e12 / (sig_ms * 1e-3))
+                         if sig_ms else None,
+                         "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz simple int32 lane-ops; frac can exceed 1 because "
+                                 "v_mad_u64_u32 / v_add3 / v_bitop3 retire 2-5 of SURVEY 8(d)'s elementary ops per issue; "
+                                 "issue_slot_utilisation = modelled minimum issue time / measured time (DESIGN.md); "
+                                 "HBM traffic per launch from PMC: profiles/r1_pmc_sig (text read ~once, 4K B/doc written)"},
         }
         if cpu is not None:
             res["cpu_baseline"] = cpu
