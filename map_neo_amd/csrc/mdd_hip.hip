@@ -102,6 +102,15 @@ struct Mt19937 {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rol(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 
+// x ^ y ^ z in one v_bitop3_b32 -- unless an operand is a compile-time zero (message words
+// the caller set to literal 0), where the builtin would not fold and a plain xor is cheaper.
+__device__ __forceinline__ uint32_t xor3(uint32_t x, uint32_t y, uint32_t z) {
+    if (__builtin_constant_p(x) && x == 0u) return y ^ z;
+    if (__builtin_constant_p(y) && y == 0u) return x ^ z;
+    if (__builtin_constant_p(z) && z == 0u) return x ^ y;
+    return __builtin_amdgcn_bitop3_b32(x, y, z, 0x96);
+}
+
 // 80 rounds over a 16-word circular schedule; fully unrolled so that message words the
 // caller set to literal 0 fold away (a 13-byte ASCII shingle has 11 zero words of 16).
 __device__ __forceinline__ void sha1_compress(uint32_t (&st)[5], uint32_t (&w)[16]) {
@@ -111,7 +120,7 @@ __device__ __forceinline__ void sha1_compress(uint32_t (&st)[5], uint32_t (&w)[1
         // v_bitop3_b32 (gfx950): any 3-input boolean in one instruction.  0x96 = x^y^z,
         // 0xCA = Ch, 0xE8 = Maj.  Measured: -14 % SHA-1 time vs the two-xor forms.
         if (t >= 16) {
-            uint32_t x = __builtin_amdgcn_bitop3_b32(w[(t - 3) & 15], w[(t - 8) & 15], w[(t - 14) & 15], 0x96) ^ w[t & 15];
+            uint32_t x = xor3(w[(t - 3) & 15], w[(t - 8) & 15], w[(t - 14) & 15]) ^ w[t & 15];
             w[t & 15] = rol(x, 1);
         }
         uint32_t f, k;
