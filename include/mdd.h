@@ -57,6 +57,11 @@ const char* mdd_last_error(void);
 int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out);
 int mdd_ctx_destroy(mdd_ctx* ctx);
 int mdd_ctx_sync(mdd_ctx* ctx);
+/* Long documents: mdd_signatures cuts a document longer than `seg_bytes` (default 16384, a
+ * multiple of 256; 0 restores the default) into segments hashed by different waves whose
+ * minima are combined with atomicMin -- results are identical, only load balance changes.
+ * The context owns the small segment queue (8 MiB, allocated by mdd_ctx_create). */
+int mdd_ctx_set_segment_bytes(mdd_ctx* ctx, uint32_t seg_bytes);
 
 /* Permutation table.  Replaces datasketch MinHash.__init__/_init_permutations, which the
  * reference re-runs for every document through `MinHash(num_perm=128)` (EN:62, ZH-1:28):

@@ -27,6 +27,10 @@ struct mdd_ctx {
     hipStream_t stream;
     bool owns_stream;
     int cus;
+    // long-document segment plan (filled by seg_plan_kernel on every mdd_signatures call)
+    uint64_t* seg_items;    // device, SEG_ITEM_CAP entries of (doc << 24 | segment)
+    uint64_t* seg_n_items;  // device counter
+    uint32_t seg_bytes;     // segment length in bytes (multiple of 256)
 };
 
 namespace {
@@ -258,6 +262,8 @@ __device__ __forceinline__ void wave_sync() {  // order this wave's LDS traffic 
 #endif
 constexpr int WAVES = MDD_WAVES;  // waves (= documents in flight) per workgroup; 1 frees a wave slot as soon as its document ends
 constexpr int RING = 512;        // code-point / token boundary ring per wave (entries)
+constexpr uint64_t SEG_ITEM_CAP = 1u << 20;     // extra segments one mdd_signatures call can queue
+constexpr uint32_t SEG_BYTES_DEFAULT = 16384;   // documents longer than this are cut into segments
 constexpr uint32_t FAST_GUARD = 8u;
 
 struct __attribute__((aligned(16))) WaveLds {
@@ -280,6 +286,12 @@ struct SigArgs {
     const uint64_t* a;
     const uint64_t* b;
     uint32_t* sig;
+    // documents longer than seg_bytes are cut into segments of shingle START offsets; segment 0
+    // belongs to the document's own wave, segments >= 1 are listed in items[] (doc << 24 | seg)
+    uint32_t seg_bytes;
+    const uint64_t* items;
+    const uint64_t* n_items;
+    uint64_t max_items;
     // DUMP mode (mdd_shingle_hashes): one document, hashes written in shingle order
     uint64_t doc_begin, doc_end;
     uint32_t* dump;
@@ -297,8 +309,16 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const uint32_t lane = lane_id();
     WaveLds& lds = lds_all[wave];
 
+    // whole waves exit early below; no workgroup barrier is used anywhere in this kernel
     uint64_t d = (uint64_t)blockIdx.x * WAVES + wave;
-    if (!DUMP && d >= A.n_docs) return;  // whole wave exits; no workgroup barrier is used anywhere
+    uint32_t seg = 0;
+    if (!DUMP && d >= A.n_docs) {
+        uint64_t idx = d - A.n_docs;
+        if (idx >= A.max_items || idx >= *A.n_items) return;
+        uint64_t it = A.items[idx];
+        d = it >> 24;
+        seg = (uint32_t)it & 0xFFFFFFu;
+    }
 
     uint64_t beg, end;
     if (DUMP) {
@@ -309,6 +329,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         end = A.offsets[d + 1];
     }
     const uint32_t len = (uint32_t)(end - beg);
+    const uint32_t seg_len = DUMP ? 0xFFFFFFFFu : A.seg_bytes;
+    const bool split = len > seg_len;  // this wave handles shingles whose first byte lies in [seg_beg, seg_end)
+    const uint32_t seg_beg = seg * seg_len;
+    const uint32_t seg_end = (uint64_t)seg_beg + seg_len < len ? seg_beg + seg_len : len;
     const int unit = A.unit;
     const uint32_t width = (uint32_t)A.width;
     const uint8_t* text = A.text;
@@ -339,8 +363,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     if (unit == MDD_UNIT_CHAR) {
         uint32_t acc = 0;
         if (len) {
-            uint32_t d1 = (boff + len - 1u) >> 2;  // dwords touching the doc (may include neighbours: conservative)
-            for (uint32_t i = lane; i <= d1; i += 64) acc |= tv.docw[i];
+            // bytes the segment's shingles can touch; whole dwords (may include neighbours: conservative)
+            uint32_t hi = (uint64_t)seg_end + width < len ? seg_end + width : len;
+            uint32_t d0 = (boff + seg_beg) >> 2, d1 = (boff + hi - 1u) >> 2;
+            for (uint32_t i = d0 + lane; i <= d1; i += 64) acc |= tv.docw[i];
         }
         ascii = __ballot((acc & 0x80808080u) != 0u) == 0ull;
     }
@@ -354,11 +380,19 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         for (int q = 0; q < KPL; q++) m[q] = 0xFFFFFFFFu;
 
         // ring state (wave-uniform)
-        uint32_t n_entS = 0, n_entE = 0, pos = 0;
-        bool scan_done = false;
+        uint32_t n_entS = 0, n_entE = 0, pos = seg_beg;
+        bool scan_done = false, seg_done = false;
+        // word unit: a segment that begins inside a token sees that token's END but not its
+        // START; drop that first end so that ringS[k] / ringE[k] keep describing the same token
+        bool skip_end = unit != MDD_UNIT_CHAR && seg_beg > 0 && seg_beg < len && text[beg + seg_beg - 1] != 0x20 &&
+                        text[beg + seg_beg] != 0x20;
         const uint32_t look = unit == MDD_UNIT_CHAR ? width : width - 1;
         uint32_t n_done = 0;
-        const uint32_t ascii_total = (ascii && len >= width) ? len - width + 1 : 0;
+        uint32_t ascii_total = 0;  // shingles of this segment when boundaries are implicit
+        if (ascii && len >= width) {
+            uint32_t j_end = len - width + 1 < seg_end ? len - width + 1 : seg_end;
+            ascii_total = j_end > seg_beg ? j_end - seg_beg : 0;
+        }
 
         for (;;) {
             uint32_t nvalid;
@@ -368,7 +402,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 uint32_t rest = ascii_total - n_done;
                 nvalid = rest < 64u ? rest : 64u;
                 if (nvalid == 0) break;
-                uint32_t j = n_done + (lane < nvalid ? lane : 0u);
+                uint32_t j = seg_beg + n_done + (lane < nvalid ? lane : 0u);
                 s = boff + j;
                 L = width;
             } else {
@@ -411,13 +445,24 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                             tot_e += (uint32_t)__popcll(be);
                         }
                     }
-                    uint32_t rs = n_entS + rank_s, re = n_entE + rank_e;
+                    uint32_t rs = n_entS + rank_s, re = rank_e;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if ((fs >> k) & 1u) lds.ringS[(rs++) & (RING - 1)] = p0 + k;
-                        if (unit != MDD_UNIT_CHAR && ((fe >> k) & 1u)) lds.ringE[(re++) & (RING - 1)] = p0 + k + 1;
+                        if (unit != MDD_UNIT_CHAR && ((fe >> k) & 1u)) {
+                            uint32_t idx = re++;
+                            if (skip_end) {
+                                if (idx == 0) continue;
+                                idx -= 1;
+                            }
+                            lds.ringE[(n_entE + idx) & (RING - 1)] = p0 + k + 1;
+                        }
                     }
                     n_entS += tot_s;
+                    if (skip_end && tot_e) {
+                        tot_e -= 1;
+                        skip_end = false;
+                    }
                     n_entE += tot_e;
                     pos += 256u;
                     if (pos >= len) {
@@ -432,11 +477,24 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
                 uint32_t rest = n_ent > n_done + look ? n_ent - look - n_done : 0u;
                 nvalid = rest < 64u ? rest : 64u;
-                if (nvalid == 0) break;
+                if (nvalid == 0 || seg_done) break;
                 uint32_t j = n_done + (lane < nvalid ? lane : 0u);
                 uint32_t sb = lds.ringS[j & (RING - 1)];
                 uint32_t eb = unit == MDD_UNIT_CHAR ? lds.ringS[(j + look) & (RING - 1)]
                                                     : lds.ringE[(j + look) & (RING - 1)];
+                if (split) {  // units that start at or after seg_end belong to the next segment (starts ascend)
+                    uint32_t nin = (uint32_t)__popcll(__ballot(lane < nvalid && sb < seg_end));
+                    if (nin < nvalid) {
+                        seg_done = true;
+                        nvalid = nin;
+                        if (nvalid == 0) break;
+                        if (lane >= nvalid) {
+                            sb = lds.ringS[n_done & (RING - 1)];
+                            eb = unit == MDD_UNIT_CHAR ? lds.ringS[(n_done + look) & (RING - 1)]
+                                                       : lds.ringE[(n_done + look) & (RING - 1)];
+                        }
+                    }
+                }
                 s = boff + sb;
                 L = eb - sb;
             }
@@ -531,8 +589,26 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int q = 0; q < KPL; q++) {
         uint32_t pi = q * 64 + lane;
-        if ((int)pi < A.K) A.sig[d * (uint64_t)A.K + pi] = m[q];
+        if ((int)pi < A.K) {
+            if (!split) A.sig[d * (uint64_t)A.K + pi] = m[q];
+            else if (n_sh_total) atomicMin(&A.sig[d * (uint64_t)A.K + pi], m[q]);  // row preset by seg_plan_kernel
+        }
     }
+}
+
+// One thread per document: documents longer than seg_bytes get their extra segments queued
+// and their signature row preset to 0xFFFFFFFF (their segments combine with atomicMin).
+__global__ void __launch_bounds__(256) seg_plan_kernel(const uint64_t* offsets, uint64_t n_docs, uint32_t seg_bytes, uint64_t* items,
+                                                       unsigned long long* n_items, uint64_t max_items, uint32_t* sig, int K) {
+    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_docs) return;
+    uint64_t len = offsets[d + 1] - offsets[d];
+    if (len <= seg_bytes) return;
+    uint64_t nseg = (len + seg_bytes - 1) / seg_bytes;
+    unsigned long long base = atomicAdd(n_items, (unsigned long long)(nseg - 1));
+    for (uint64_t k = 1; k < nseg; k++)
+        if (base + k - 1 < max_items) items[base + k - 1] = (d << 24) | k;
+    for (int q = 0; q < K; q++) sig[d * (uint64_t)K + q] = 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -829,12 +905,21 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     // NULL is HIP's default (null) stream -- the stream torch uses unless told otherwise
     c->stream = (hipStream_t)hip_stream;
     c->owns_stream = false;
+    c->seg_bytes = SEG_BYTES_DEFAULT;
+    c->seg_items = nullptr;
+    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 1) * sizeof(uint64_t));
+    if (me != hipSuccess) {
+        delete c;
+        return fail(MDD_ERR_HIP, "mdd_ctx_create: hipMalloc of the segment plan failed: %s", hipGetErrorString(me));
+    }
+    c->seg_n_items = c->seg_items + SEG_ITEM_CAP;
     *out = c;
     return MDD_OK;
 }
 
 int mdd_ctx_destroy(mdd_ctx* ctx) {
     if (!ctx) return MDD_OK;
+    if (ctx->seg_items) (void)hipFree(ctx->seg_items);
     delete ctx;
     return MDD_OK;
 }
@@ -842,6 +927,14 @@ int mdd_ctx_destroy(mdd_ctx* ctx) {
 int mdd_ctx_sync(mdd_ctx* ctx) {
     REQUIRE(ctx != nullptr, "mdd_ctx_sync: ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MDD_OK;
+}
+
+int mdd_ctx_set_segment_bytes(mdd_ctx* ctx, uint32_t seg_bytes) {
+    REQUIRE(ctx != nullptr, "mdd_ctx_set_segment_bytes: ctx is NULL");
+    if (seg_bytes == 0) seg_bytes = SEG_BYTES_DEFAULT;
+    REQUIRE(seg_bytes >= 256 && seg_bytes % 256 == 0, "mdd_ctx_set_segment_bytes: %u is not a positive multiple of 256", seg_bytes);
+    ctx->seg_bytes = seg_bytes;
     return MDD_OK;
 }
 
@@ -863,7 +956,7 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
     REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "mdd_signatures: K=%d outside [1,%d]", K, MDD_MAX_PERM);
     if (n_docs == 0) return MDD_OK;
     REQUIRE(offsets && a && b && sig_out, "mdd_signatures: NULL pointer argument");
-    REQUIRE(n_docs <= 0x7FFFFFFFull * WAVES, "mdd_signatures: n_docs=%llu too large for one launch",
+    REQUIRE(n_docs <= 0x7FF00000ull * WAVES && n_docs < (1ull << 40), "mdd_signatures: n_docs=%llu too large for one launch",
             (unsigned long long)n_docs);
     HIP_TRY(hipSetDevice(ctx->device));
     SigArgs A{};
@@ -877,7 +970,23 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
     A.a = a;
     A.b = b;
     A.sig = sig_out;
-    return launch_sig<false>(ctx, A, grid_for(n_docs, WAVES));
+    // segment plan: seg_bytes grows for huge inputs so that the extra segments always fit the queue
+    uint64_t seg = ctx->seg_bytes;
+    uint64_t need = text_bytes / SEG_ITEM_CAP + 1;
+    if (seg < need) seg = need;
+    seg = (seg + 255) / 256 * 256;
+    REQUIRE(seg <= 0xFFFFFF00ull, "mdd_signatures: text too large for the segment plan");
+    uint64_t max_items = text_bytes / seg;  // sum over docs of (ceil(len/seg) - 1) <= text_bytes / seg
+    if (max_items > SEG_ITEM_CAP) max_items = SEG_ITEM_CAP;
+    A.seg_bytes = (uint32_t)seg;
+    A.items = ctx->seg_items;
+    A.n_items = ctx->seg_n_items;
+    A.max_items = max_items;
+    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, A.seg_bytes,
+                       ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, sig_out, K);
+    HIP_TRY(hipGetLastError());
+    return launch_sig<false>(ctx, A, grid_for(n_docs + max_items, WAVES));
 }
 
 int mdd_shingle_hashes(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, uint64_t doc_begin, uint64_t doc_end,

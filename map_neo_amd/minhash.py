@@ -101,6 +101,10 @@ class Engine:
         except Exception:
             pass
 
+    def set_segment_bytes(self, seg_bytes: int = 0):
+        """Documents longer than this are split across waves (0 = library default)."""
+        _lib.check(self.L.mdd_ctx_set_segment_bytes(self.ctx, int(seg_bytes)), "mdd_ctx_set_segment_bytes")
+
     def sync(self):
         _lib.check(self.L.mdd_ctx_sync(self.ctx), "mdd_ctx_sync")
 

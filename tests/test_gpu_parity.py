@@ -243,3 +243,59 @@ def test_routed_packed_path(engine, mini_docs, mini_expected, world):
         start += c
     engine.components_finish(labels)
     assert (as_u32(labels) == mini_expected["labels_b9_r13_K128"]).all()
+
+
+@pytest.mark.parametrize("seg", [256, 512, 1024])
+def test_long_document_segments_forced(engine, mini_docs, mini_expected, seg):
+    """cut documents into tiny segments (several waves + atomicMin per document): results must
+    not change -- ASCII, CJK, emoji and mixed documents, char and word units"""
+    text, offs_d, _, _ = _dev(engine, mini_docs)
+    engine.set_segment_bytes(seg)
+    try:
+        for name, K, width, unit in [("sig_char13_K256", 256, 13, "char"), ("sig_word5_K128", 128, 5, "word"),
+                                     ("sig_char5_K128", 128, 5, "char"), ("sig_char20_K64", 64, 20, "char")]:
+            sig = as_u32(engine.signatures(text, offs_d, K, width, unit))
+            assert (sig == mini_expected[name]).all(), (seg, name)
+    finally:
+        engine.set_segment_bytes(0)
+
+
+def test_long_documents_default_segments(engine):
+    """documents of 20 KB .. 400 KB (C5-like and beyond) with the default segment length"""
+    rng = np.random.Generator(np.random.PCG64(17))
+    words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "iota", "kappa", "lambda", "mu"]
+    cjk = [chr(0x4E00 + i) for i in range(3000)]
+    docs = []
+    for i in range(24):
+        n = int(rng.integers(20_000, 400_000))
+        if i % 3 == 0:
+            docs.append(" ".join(rng.choice(words, n // 6)))
+        elif i % 3 == 1:
+            docs.append("".join(rng.choice(cjk, n // 3)))
+        else:
+            parts = []
+            for _ in range(n // 40):
+                parts.append(" ".join(rng.choice(words, 3)) if rng.random() < 0.5 else "".join(rng.choice(cjk, 8)) + "😀")
+            docs.append(" ".join(parts))
+    docs += ["short one", docs[0], docs[1][:50_000]]
+    text, offs_d, buf, offs = _dev(engine, docs)
+    for K, width, unit in ((128, 13, "char"), (128, 5, "word")):
+        got = as_u32(engine.signatures(text, offs_d, K, width, unit))
+        exp = RC.signatures(buf, offs, K, width, unit)
+        assert (got == exp).all(), (K, width, unit)
+    for (b, r, K) in [(9, 13, 128), (14, 9, 128), (20, 12, 256)]:       # C5 band sweep
+        out = dedup_local(engine, text, offs_d, K, 13, "char", b, r)
+        exp_sig = RC.signatures(buf, offs, K, 13, "char")
+        exp_labels, _ = RC.cluster(exp_sig, b, r)
+        assert (as_u32(out["labels"]) == exp_labels).all()
+
+
+def test_c1_word5_config(engine):
+    """BASELINE.json configs[0]: 10k synthetic English docs, 5-gram words, num_perm=128 -- GPU vs the CPU path"""
+    spec = corpus.CorpusSpec(10000, 2048, seed=20240519 + 1, lang="en")
+    text, offs = corpus.generate(spec, device=engine.device)
+    out = dedup_local(engine, text, offs, 128, 5, "word", 9, 13)
+    exp_sig = RC.signatures(text.cpu().numpy(), offs.cpu().numpy().astype(np.uint64), 128, 5, "word")
+    assert (as_u32(out["sig"]) == exp_sig).all()
+    exp_labels, _ = RC.cluster(exp_sig, 9, 13)
+    assert (as_u32(out["labels"]) == exp_labels).all()
