@@ -17,6 +17,8 @@ int main(int argc, char** argv) {
     double sigma = argc > 3 ? atof(argv[3]) / 100.0 : 0.6;
     int K = argc > 4 ? atoi(argv[4]) : 128;
     int lang = argc > 5 ? atoi(argv[5]) : 0;
+    int unit = argc > 6 ? atoi(argv[6]) : 0;
+    int width = argc > 7 ? atoi(argv[7]) : 13;
     std::mt19937_64 rng(12345);
     std::lognormal_distribution<double> ln(std::log(mean) - 0.5 * sigma * sigma, sigma);
     std::vector<uint64_t> offs(n + 1, 0);
@@ -61,7 +63,7 @@ int main(int argc, char** argv) {
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
         CK(hipEventRecord(e0, 0));
-        if (mdd_signatures(ctx, dt, total, doff, n, 0, 13, K, da, db, dsig)) { fprintf(stderr, "%s\n", mdd_last_error()); return 1; }
+        if (mdd_signatures(ctx, dt, total, doff, n, unit, width, K, da, db, dsig)) { fprintf(stderr, "%s\n", mdd_last_error()); return 1; }
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -71,6 +73,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(sig.data(), dsig, n * K * 4, hipMemcpyDeviceToHost));
     uint64_t cks = 0;
     for (uint64_t i = 0; i < n * K; i++) cks = cks * 1099511628211ull + sig[i];
+    printf("unit=%d width=%d ", unit, width);
     printf("n=%llu bytes=%llu shingles=%llu K=%d sigma=%.2f lang=%d  ms=%.3f  Gsh/s=%.2f  Mdocs/s=%.2f  cks=%016llx\n",
            (unsigned long long)n, (unsigned long long)total, (unsigned long long)nsh, K, sigma, lang, best, nsh / best / 1e6,
            n / best / 1e3, (unsigned long long)cks);
