@@ -817,14 +817,19 @@ __global__ void __launch_bounds__(256) uf_flatten_kernel(uint32_t* parent, uint6
 
 __global__ void __launch_bounds__(256) removed_kernel(const uint32_t* labels, uint64_t first, uint64_t n, uint8_t* removed,
                                                       unsigned long long* n_removed) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool rm = false;
-    if (i < n) {
-        rm = labels[first + i] != (uint32_t)(first + i);
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    // grid-stride so that one block handles many documents and issues ONE global atomic
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        bool rm = labels[first + i] != (uint32_t)(first + i);
         removed[i] = rm ? 1 : 0;
+        mine += rm;
     }
-    uint64_t bal = __ballot(rm);
-    if (bal && lane_id() == (uint32_t)(__ffsll((unsigned long long)bal) - 1)) atomicAdd(n_removed, (unsigned long long)__popcll(bal));
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(n_removed, (unsigned long long)cnt);
 }
 
 // VALU calibration: dependency-free fast-class int32 ops (v_xor / v_add / v_lshrrev)
@@ -1139,7 +1144,9 @@ int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint6
     HIP_TRY(hipMemsetAsync(n_removed, 0, sizeof(uint64_t), ctx->stream));
     if (n == 0) return MDD_OK;
     REQUIRE(labels && removed, "mdd_removed_mask: NULL buffer");
-    hipLaunchKernelGGL(removed_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, labels, first, n, removed,
+    unsigned rg = grid_for(n, 256);
+    if (rg > 4096u) rg = 4096u;
+    hipLaunchKernelGGL(removed_kernel, dim3(rg), dim3(256), 0, ctx->stream, labels, first, n, removed,
                        reinterpret_cast<unsigned long long*>(n_removed));
     HIP_TRY(hipGetLastError());
     return MDD_OK;

@@ -181,10 +181,10 @@ def test_empty_and_degenerate_inputs(engine):
 
 
 def test_full_size_properties(engine):
-    """C2-shaped shard (200k docs ~2 KB): size-independent properties instead of a full oracle run:
+    """C2 at full size (1M docs ~2 KB, BASELINE.json configs[1]): size-independent properties instead of a full oracle run:
     exact copies get identical signatures and one component; K=128 is a prefix of K=256;
     a sample of documents matches the oracle bit for bit; n_removed = sum(|component|-1)."""
-    spec = corpus.CorpusSpec(200000, 2048, lang="en", dup_frac=0.15, edit_rate=0.0)   # edit_rate 0: exact copies
+    spec = corpus.CorpusSpec(1_000_000, 2048, lang="en", dup_frac=0.15, edit_rate=0.0)   # edit_rate 0: exact copies
     text, offs = corpus.generate_chunked(spec, engine.device)
     out = dedup_local(engine, text, offs)
     sig = out["sig"]
