@@ -538,8 +538,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                             for (int q = 0; q < KPL; q++) {
                                 uint64_t b1 = (((uint64_t)bhi[q] << 32) | blo[q]) + 1ull;
                                 uint64_t t = (uint64_t)alo[q] * hh[e] + b1;
-                                // hipcc fuses this into a second v_mad_u64_u32; a hand-placed
-                                // v_mul_lo_u32 + v_add_u32 measured 7 % slower
+                                // hipcc fuses this into a second v_mad_u64_u32 (+ v_mov).  Measured
+                                // alternatives, both slower: v_mul_lo_u32 + v_add_u32 (-7 %), and
+                                // pre-adding a_hi*h into the high half of the first mad's addend
+                                // (hipcc turns it into mad + mov + v_lshl_add_u64).
                                 uint32_t thi = (uint32_t)(t >> 32) + ahi[q] * hh[e];
                                 uint32_t sv = (uint32_t)t + (thi >> 29);
                                 m[q] = sv < m[q] ? sv : m[q];
