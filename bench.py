@@ -205,6 +205,16 @@ def main():
         n_removed = int(nr.item())
 
     if rank == 0:
+        # HBM bytes per sig_kernel launch from the PMC passes of this same command (tools/pmc_bench.sh ->
+        # profiles/r1_pmc_bench/summary.json, FETCH_SIZE corrected x2 as calibrated); null if the workload differs
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_bench", "summary.json")))
+            if pm["workload"]["text_bytes_per_gpu"] == text_bytes and pm["workload"]["docs_per_gpu"] == n_local:
+                k = pm["kernels"]["sig_kernel<2, false>"]
+                traffic = k["fetch_bytes"] + k["write_bytes"]
+        except Exception:
+            traffic = None
         ms_per_step = dt / args.steps * 1e3
         sig_ms = stages.get("signatures", 0.0) / args.steps       # HIP events on the launch stream, timed region
         achieved = n_shingles * OPS_PER_SHINGLE(K) / (sig_ms * 1e-3) / 1e12 if sig_ms else None
@@ -234,14 +244,15 @@ def main():
             "pcie_inclusive_docs_per_s": (n_local / ((ms_per_step + h2d_ms) * 1e-3)) if (h2d_ms and world == 1) else None,
             "roofline": {"bound": "valu", "kernel": "sig_kernel<2,false>", "achieved": achieved, "peak": PEAK_VALU_TOPS,
                          "unit": "Tops/s (int32 lane-ops)", "frac": (achieved / PEAK_VALU_TOPS) if achieved else None,
-                         "traffic": None, "kernel_ms": sig_ms,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                         "algorithmic_bytes": text_bytes + 8 * (n_local + 1) + 4 * K * n_local, "kernel_ms": sig_ms,
                          "algorithmic_ops_per_shingle": OPS_PER_SHINGLE(K),
                          "issue_slot_utilisation": (n_shingles * ISSUE_SLOTS_PER_SHINGLE(K) / 78.6e12 / (sig_ms * 1e-3))
                          if sig_ms else None,
                          "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz simple int32 lane-ops; frac can exceed 1 because "
                                  "v_mad_u64_u32 / v_add3 / v_bitop3 retire 2-5 of SURVEY 8(d)'s elementary ops per issue; "
                                  "issue_slot_utilisation = modelled minimum issue time / measured time (DESIGN.md); "
-                                 "HBM traffic per launch from PMC: profiles/r1_pmc_sig (text read ~once, 4K B/doc written)"},
+                                 "traffic from profiles/r1_pmc_bench/summary.json"},
         }
         if cpu is not None:
             res["cpu_baseline"] = cpu
