@@ -237,6 +237,62 @@ class Engine:
         return out.value
 
 
+class HostPipeline:
+    """Signatures for a corpus that lives in (pinned) HOST memory: documents are cut into
+    batches, batch b+1 is copied over PCIe on a copy stream while batch b is hashed on the
+    compute stream (two device staging buffers, events both ways), so the PCIe time hides
+    behind the VALU-bound kernel.  One mdd context per stream (contexts are bound to a stream)."""
+
+    def __init__(self, engine: "Engine", batch_bytes: int = 256 << 20):
+        self.eng = engine
+        self.batch_bytes = int(batch_bytes)
+        self.copy_stream = torch.cuda.Stream(device=engine.device)
+
+    def signatures(self, text_host: torch.Tensor, offsets_host: np.ndarray, num_perm: int = NUM_PERM,
+                   width: int = WIDTH, unit: str = "char", seed: int = SEED) -> torch.Tensor:
+        eng = self.eng
+        offs = np.ascontiguousarray(offsets_host).astype(np.int64)
+        n = offs.shape[0] - 1
+        sig = torch.empty((n, num_perm), dtype=torch.int32, device=eng.device)
+        if n == 0:
+            return sig
+        # batch boundaries: whole documents, about batch_bytes each
+        cuts = [0]
+        while cuts[-1] < n:
+            target = offs[cuts[-1]] + self.batch_bytes
+            nxt = int(np.searchsorted(offs, target, side="right")) - 1
+            cuts.append(min(n, max(nxt, cuts[-1] + 1)))
+        max_bytes = max(int(offs[b] - offs[a]) for a, b in zip(cuts[:-1], cuts[1:]))
+        max_docs = max(b - a for a, b in zip(cuts[:-1], cuts[1:]))
+        bufs = [torch.zeros(padded_size(max_bytes), dtype=torch.uint8, device=eng.device) for _ in range(2)]
+        obufs = [torch.empty(max_docs + 1, dtype=torch.int64, device=eng.device) for _ in range(2)]
+        ohost = [torch.empty(max_docs + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
+        copied = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+        a_d, b_d = eng.perms(seed, num_perm)
+        compute = torch.cuda.current_stream(eng.device)
+        host_free = [None, None]
+        for i, (d0, d1) in enumerate(zip(cuts[:-1], cuts[1:])):
+            s = i & 1
+            lo, hi = int(offs[d0]), int(offs[d1])
+            nd = d1 - d0
+            if host_free[s] is not None:
+                host_free[s].synchronize()            # pinned offsets staging of batch i-2 has been read
+            ohost[s][: nd + 1].copy_(torch.from_numpy(offs[d0:d1 + 1] - lo))
+            with torch.cuda.stream(self.copy_stream):
+                if i >= 2:
+                    self.copy_stream.wait_event(consumed[s])      # kernel of batch i-2 is done with this buffer
+                bufs[s][: hi - lo].copy_(text_host[lo:hi], non_blocking=True)
+                obufs[s][: nd + 1].copy_(ohost[s][: nd + 1], non_blocking=True)
+                copied[s].record(self.copy_stream)
+                host_free[s] = copied[s]
+            compute.wait_event(copied[s])
+            eng.signatures(bufs[s], obufs[s][: nd + 1], num_perm, width, unit, seed, perms=(a_d, b_d),
+                           text_bytes=hi - lo, out=sig[d0:d1])
+            consumed[s].record(compute)
+        return sig
+
+
 def resolve_collisions(coll_idx: np.ndarray, meta_h: np.ndarray, tuple_of) -> Tuple[np.ndarray, np.ndarray]:
     """Exact fallback for records whose 64-bit surrogate key collided with a different tuple
     (expected count ~ n_rec^2 / 2^64).  Every record carrying the same (band, tuple) as a

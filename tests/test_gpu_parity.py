@@ -299,3 +299,16 @@ def test_c1_word5_config(engine):
     assert (as_u32(out["sig"]) == exp_sig).all()
     exp_labels, _ = RC.cluster(exp_sig, 9, 13)
     assert (as_u32(out["labels"]) == exp_labels).all()
+
+
+def test_host_pipeline_matches_resident(engine):
+    """copy/compute overlap path: corpus in pinned host memory, batches over PCIe on a copy stream"""
+    from map_neo_amd.minhash import HostPipeline
+    spec = corpus.CorpusSpec(30000, 700, lang="mixed", dup_frac=0.1)
+    text, offs = corpus.generate(spec, device=engine.device)
+    ref = engine.signatures(text, offs, 128)
+    host = text.cpu().pin_memory()
+    pipe = HostPipeline(engine, batch_bytes=1 << 20)          # ~20 batches
+    got = pipe.signatures(host, offs.cpu().numpy(), 128)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
