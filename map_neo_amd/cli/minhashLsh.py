@@ -8,20 +8,29 @@
 Input : directory of JSON-lines files (optionally .gz) with `doc_id` and the content field
         (EN:120-123).
 Inter : signatures keyed by doc_id (EN:128-129 writes a Spark pickle SequenceFile of
-        (uint64[128], doc_id); here: signatures.npy (uint32 [n, K]) + doc_ids.json).
-Output: gzip JSON lines of the surviving rows with all original columns (EN:149-150) and
-        the line "the number of doc need to be remove is  N" (EN:148).
+        (uint64[128], doc_id); here: signatures.npy (uint32 [n, K]) + doc_ids.json, rows in
+        input order).
+Output: gzip JSON lines of the surviving rows with all original columns (EN:149-150), one
+        part file per input file, and the line "the number of doc need to be remove is  N"
+        (EN:148).
 Rows whose content is null are never hashed and therefore always kept (EN:124).  Within a
 connected component the row(s) carrying the smallest doc_id (Python ordering) survive
 (EN:145: remove_list = first element of every final (v, min) edge).
+
+Two streaming passes, so memory holds signatures and doc_ids but never the corpus:
+  pass 1  a process pool parses + normalises one file per task (host work, EN:31-40) and
+          returns packed utf-8; the main process feeds the GPU file by file (signatures stay
+          in HBM);   then bands -> buckets -> union-find on the GPU;
+  pass 2  the pool re-reads every file and writes the rows whose doc_id survives.
 Extension flags (defaults = the reference's constants EN:17-20): --width --ngram_unit
---num_perm --bands --rows --seed --device.
+--num_perm --bands --rows --seed --device --workers.
 """
 from __future__ import annotations
 
 import argparse
 import gzip
 import json
+import multiprocessing as mp
 import os
 import sys
 import time
@@ -42,72 +51,123 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--rows", type=int, default=13)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
     return p
 
 
-def minhashLsh(args) -> dict:
-    import torch
-
+def _parse_file(task):
+    """pool worker, pass 1: (doc_ids of all rows, indices of candidate rows, packed text, offsets)"""
+    path, field = task
     from .. import hostio
-    from ..dedup import dedup_local
-    from ..minhash import Engine, as_u32, pack_texts
+    ids, cand, enc = [], [], []
+    for line in hostio.iter_lines(path):
+        if not line.strip():
+            continue
+        row = json.loads(line)
+        text = row.get(field)
+        if text is not None and hostio.encodable(text):        # EN:124 null filter; un-encodable text is skipped
+            cand.append(len(ids))
+            enc.append(hostio.normalize_text(text).encode("utf8"))
+        ids.append(row.get("doc_id"))
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+    return path, ids, np.asarray(cand, dtype=np.int64), np.frombuffer(b"".join(enc), dtype=np.uint8), offs
 
-    t0 = time.time()
-    rows, srcs = [], []
-    for path in hostio.list_files(args.input_dir):
-        for line in hostio.iter_lines(path):
-            if line.strip():
-                rows.append(json.loads(line))
-    field = args.content_field_name
-    # candidates = rows with non-null content (EN:124); sorted by doc_id so that
-    # "smallest dense index of a component" == "smallest doc_id of a component" (EN:145)
-    cand = [i for i, r in enumerate(rows) if r.get(field) is not None and hostio.encodable(r[field])]
-    cand.sort(key=lambda i: rows[i]["doc_id"])
-    texts = [hostio.normalize_text(rows[i][field]) for i in cand]
-    ids = [rows[i]["doc_id"] for i in cand]
-    t1 = time.time()
 
-    eng = Engine(args.device)
-    buf, offs = pack_texts(texts)
-    out = dedup_local(eng, eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width, args.ngram_unit,
-                      args.bands, args.rows, args.seed, text_bytes=int(offs[-1]))
-    labels = as_u32(out["labels"])
-    # rows sharing one doc_id are one node of the reference's graph: they are adjacent after
-    # the sort; link them, then re-label through the union-find on the host (tiny)
-    dup_id_edges = [(k + 1, k) for k in range(len(ids) - 1) if ids[k] == ids[k + 1]]
-    if dup_id_edges:
-        lab = eng.components_init(len(ids))
-        eng.components_union(lab, out["edge_u"], out["edge_v"])
-        eu = eng.to_device(np.asarray([e[0] for e in dup_id_edges], np.uint32))
-        ev = eng.to_device(np.asarray([e[1] for e in dup_id_edges], np.uint32))
-        eng.components_union(lab, eu, ev)
-        eng.components_finish(lab)
-        labels = as_u32(lab)
-    sig = as_u32(out["sig"])
-    t2 = time.time()
-
-    os.makedirs(args.inter_dir, exist_ok=True)
-    np.save(os.path.join(args.inter_dir, "signatures.npy"), sig)
-    with open(os.path.join(args.inter_dir, "doc_ids.json"), "w", encoding="utf8") as f:
-        json.dump(ids, f, ensure_ascii=False)
-    print("finish generate hash value")                                   # EN:132
-
-    remove_ids = {ids[k] for k in range(len(ids)) if ids[int(labels[k])] != ids[k]}
-    n_remove = len(remove_ids)
-    print("the number of doc need to be remove is ", n_remove)            # EN:148
-    os.makedirs(args.output_dir, exist_ok=True)
+def _write_file(task):
+    """pool worker, pass 2: copy the rows whose doc_id is not removed (left_anti join, EN:149)"""
+    path, out_path, remove_ids = task
+    from .. import hostio
     kept = 0
-    with gzip.open(os.path.join(args.output_dir, "part-00000.json.gz"), "wt", encoding="utf8") as f:
-        for r in rows:                                                     # left_anti join on doc_id (EN:149)
-            if r.get("doc_id") not in remove_ids:
-                f.write(json.dumps(r, ensure_ascii=False) + "\n")
+    with gzip.open(out_path, "wt", encoding="utf8") as f:
+        for line in hostio.iter_lines(path):
+            if not line.strip():
+                continue
+            row = json.loads(line)
+            if row.get("doc_id") not in remove_ids:
+                f.write(json.dumps(row, ensure_ascii=False) + "\n")
                 kept += 1
-    t3 = time.time()
-    stats = {"n_rows": len(rows), "n_candidates": len(ids), "n_remove": n_remove, "n_kept_rows": kept,
-             "n_components": int((labels == np.arange(len(ids))).sum()),
-             "t_read_normalise_s": t1 - t0, "t_gpu_s": t2 - t1, "t_write_s": t3 - t2}
+    return kept
+
+
+def minhashLsh(args) -> dict:
+    from .. import hostio
+    files = hostio.list_files(args.input_dir)
+    t0 = time.time()
+    ctx = mp.get_context("fork")                 # forked BEFORE the GPU is touched in this process
+    pool = ctx.Pool(max(1, args.workers))
+    try:
+        parsed = pool.imap(_parse_file, [(p, args.content_field_name) for p in files])
+
+        import torch
+
+        from ..dedup import cluster_local
+        from ..minhash import Engine, as_u32, padded_size
+        eng = Engine(args.device)
+        sigs, cand_ids, n_rows = [], [], 0
+        for path, ids, cand, text, offs in parsed:
+            n_rows += len(ids)
+            if len(cand):
+                buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+                buf[: text.size] = text
+                sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                                           args.ngram_unit, args.seed, text_bytes=int(text.size)))
+                cand_ids.extend(ids[i] for i in cand.tolist())
+        t1 = time.time()
+        n = len(cand_ids)
+        sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
+        out = cluster_local(eng, sig, args.bands, args.rows)
+        labels = as_u32(out["labels"])
+        # rows sharing one doc_id are ONE node of the reference's graph (its edges carry doc_ids)
+        first_of, extra = {}, []
+        for k, d in enumerate(cand_ids):
+            j = first_of.setdefault(d, k)
+            if j != k:
+                extra.append((k, j))
+        if extra:
+            lab = eng.components_init(n)
+            eng.components_union(lab, out["edge_u"], out["edge_v"])
+            e = np.asarray(extra, dtype=np.uint32)
+            eng.components_union(lab, eng.to_device(np.ascontiguousarray(e[:, 0])),
+                                 eng.to_device(np.ascontiguousarray(e[:, 1])))
+            eng.components_finish(lab)
+            labels = as_u32(lab)
+        # survivor of a component = smallest doc_id (EN:145), whatever its position in the input
+        members = np.flatnonzero(labels != np.arange(n, dtype=np.uint32))
+        comp_min = {}
+        for k in set(labels[members].tolist()) | set(members.tolist()):
+            l = int(labels[k])
+            d = cand_ids[k]
+            if l not in comp_min or d < comp_min[l]:
+                comp_min[l] = d
+        remove_ids = {cand_ids[k] for k in comp_min_members(labels, members) if cand_ids[k] != comp_min[int(labels[k])]}
+        t2 = time.time()
+
+        os.makedirs(args.inter_dir, exist_ok=True)
+        np.save(os.path.join(args.inter_dir, "signatures.npy"), as_u32(sig).reshape(n, args.num_perm))
+        with open(os.path.join(args.inter_dir, "doc_ids.json"), "w", encoding="utf8") as f:
+            json.dump(cand_ids, f, ensure_ascii=False)
+        print("finish generate hash value")                                   # EN:132
+        print("the number of doc need to be remove is ", len(remove_ids))     # EN:148 (distinct doc_ids)
+        os.makedirs(args.output_dir, exist_ok=True)
+        tasks = [(p, os.path.join(args.output_dir, "part-%05d.json.gz" % i), remove_ids) for i, p in enumerate(files)]
+        kept = sum(pool.imap_unordered(_write_file, tasks))
+        t3 = time.time()
+    finally:
+        pool.close()
+        pool.join()
+    stats = {"n_rows": n_rows, "n_candidates": n, "n_remove": len(remove_ids), "n_kept_rows": kept,
+             "n_components": int((labels == np.arange(n)).sum()) if n else 0,
+             "t_parse_normalise_signatures_s": t1 - t0, "t_cluster_s": t2 - t1, "t_write_s": t3 - t2}
     print(json.dumps(stats), file=sys.stderr)
     return stats
+
+
+def comp_min_members(labels: np.ndarray, members: np.ndarray):
+    """indices of every document that belongs to a component with more than one member"""
+    roots = set(labels[members].tolist())
+    return sorted(set(members.tolist()) | roots)
 
 
 def main(argv=None):

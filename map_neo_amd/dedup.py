@@ -56,18 +56,12 @@ class StageTimer:
         return out
 
 
-def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = NUM_PERM, width: int = WIDTH,
-                unit: str = "char", bands: int = BANDS, rows: int = ROWS, seed: int = SEED,
-                text_bytes: Optional[int] = None, key_bits: int = 64, want_buckets: bool = False,
-                timer: Optional[StageTimer] = None):
-    """One-GPU path.  Returns a dict of device tensors: sig [n,K], edge_u/edge_v, labels [n]
-    (label = smallest doc index of the component), removed [n] uint8, n_removed (device
-    int64[1]), n_collisions (host int)."""
-    n = offsets.numel() - 1
+def cluster_local(be, sig: torch.Tensor, bands: int = BANDS, rows: int = ROWS, key_bits: int = 64,
+                  want_buckets: bool = False, timer: Optional[StageTimer] = None):
+    """Band records -> buckets/edges -> union-find -> removed mask for signatures already in HBM
+    (EN:133-145 / ZH-2..ZH-4).  Document index = row of `sig`."""
+    n, num_perm = sig.shape
     mark = timer.mark if timer is not None else (lambda name: None)
-    mark("start")
-    sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
-    mark("signatures")
     key, meta = be.band_keys(sig, bands, rows, 0, key_bits)
     mark("band_keys")
     eu, ev, coll_idx, rb = be.bucket_edges(key, meta, sig, bands, num_perm, rows, rows, want_buckets)
@@ -85,6 +79,20 @@ def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = N
     return {"sig": sig, "key": key, "meta": meta, "edge_u": eu, "edge_v": ev, "labels": labels,
             "removed": removed, "n_removed": n_removed, "n_collisions": int(coll_idx.size),
             "rec_bucket": rb}
+
+
+def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = NUM_PERM, width: int = WIDTH,
+                unit: str = "char", bands: int = BANDS, rows: int = ROWS, seed: int = SEED,
+                text_bytes: Optional[int] = None, key_bits: int = 64, want_buckets: bool = False,
+                timer: Optional[StageTimer] = None):
+    """One-GPU path.  Returns a dict of device tensors: sig [n,K], edge_u/edge_v, labels [n]
+    (label = smallest doc index of the component), removed [n] uint8, n_removed (device
+    int64[1]), n_collisions (host int)."""
+    mark = timer.mark if timer is not None else (lambda name: None)
+    mark("start")
+    sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
+    mark("signatures")
+    return cluster_local(be, sig, bands, rows, key_bits, want_buckets, timer)
 
 
 def _all_to_all_v(t: torch.Tensor, send_counts, recv_counts, width: int, group=None):

@@ -35,7 +35,8 @@ def test_en_cli_end_to_end(tmp_path, mini_docs, capsys):
     with gzip.open(inp / "part-1.json.gz", "wt", encoding="utf8") as f:
         for r in rows[120:]:
             f.write(json.dumps(r, ensure_ascii=False) + "\n")
-    minhashLsh.main(["--input_dir", str(inp), "--inter_dir", str(tmp_path / "inter"), "--output_dir", str(tmp_path / "out")])
+    minhashLsh.main(["--input_dir", str(inp), "--inter_dir", str(tmp_path / "inter"), "--output_dir", str(tmp_path / "out"),
+                     "--workers", "2"])
     # oracle: EN:119-150 on the same rows
     cand = [r for r in rows if r["raw_content"] is not None]
     cand.sort(key=lambda r: r["doc_id"])
@@ -46,14 +47,17 @@ def test_en_cli_end_to_end(tmp_path, mini_docs, capsys):
     # literal star loop (EN:138-145) gives the same remove_list
     star = R.large_star_small_star(R.generate_edges(m)[i] for m in exp["buckets"].values() for i in range(len(m) - 1))
     assert {ids[u] for u, _ in star} == exp_removed
-    out_rows = [json.loads(l) for l in gzip.open(tmp_path / "out" / "part-00000.json.gz", "rt", encoding="utf8")]
+    out_rows = [json.loads(l) for part in sorted(os.listdir(tmp_path / "out"))
+                for l in gzip.open(tmp_path / "out" / part, "rt", encoding="utf8")]
     assert {r["doc_id"] for r in out_rows} == {r["doc_id"] for r in rows} - exp_removed
     assert all("meta" in r for r in out_rows)                              # all original columns survive
     assert any(r["raw_content"] is None for r in out_rows)                 # null content is always kept
     assert f"the number of doc need to be remove is  {len(exp_removed)}" in capsys.readouterr().out
     sig = np.load(tmp_path / "inter" / "signatures.npy")
-    assert json.load(open(tmp_path / "inter" / "doc_ids.json")) == ids
-    assert (sig == exp["signatures"]).all()
+    inter_ids = json.load(open(tmp_path / "inter" / "doc_ids.json"))
+    assert inter_ids == [r["doc_id"] for r in rows if r["raw_content"] is not None]     # input order
+    row_of = {d: k for k, d in enumerate(ids)}
+    assert (sig == exp["signatures"][[row_of[d] for d in inter_ids]]).all()
 
 
 def _zh_files(tmp_path, mini_docs):
@@ -109,3 +113,26 @@ def test_zh_five_steps_and_fused(tmp_path, mini_docs):
         assert (O2 / name).read_bytes() == (O / name).read_bytes()
     rep = json.load(open(tmp_path / "rep.json"))
     assert len(rep["removed"]) == int(exp["removed"].sum())
+
+
+def test_en_cli_duplicate_doc_ids(tmp_path, mini_docs, capsys):
+    """rows sharing a doc_id are one node of the reference's graph (edges carry doc_ids, EN:136-145;
+    the anti-join EN:149 drops every row of a removed id)"""
+    base = mini_docs[60]
+    rows = [{"doc_id": "b", "raw_content": base},
+            {"doc_id": "a", "raw_content": mini_docs[61]},      # unrelated text, but shares its id with a copy of base
+            {"doc_id": "a", "raw_content": base},
+            {"doc_id": "c", "raw_content": base},
+            {"doc_id": "d", "raw_content": mini_docs[62]}]
+    inp = tmp_path / "in"
+    inp.mkdir()
+    with open(inp / "x.json", "w", encoding="utf8") as f:
+        for r in rows:
+            f.write(json.dumps(r) + "\n")
+    minhashLsh.main(["--input_dir", str(inp), "--inter_dir", str(tmp_path / "m"), "--output_dir", str(tmp_path / "o"),
+                     "--workers", "1"])
+    out_rows = [json.loads(l) for part in sorted(os.listdir(tmp_path / "o"))
+                for l in gzip.open(tmp_path / "o" / part, "rt", encoding="utf8")]
+    # component {a, b, c} keeps the smallest id "a" (both of its rows); "d" is untouched
+    assert sorted(r["doc_id"] for r in out_rows) == ["a", "a", "d"]
+    assert "the number of doc need to be remove is  2" in capsys.readouterr().out
