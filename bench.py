@@ -243,7 +243,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32/u64 integer",
+            "dtype": "u32/u64",
             "data": "synthetic",
             "config": {"workload": "C2: %d synthetic English docs per GPU (~%d B avg), char 13-gram shingles, "
                                    "num_perm=128, 9 bands x 13 rows, seed 1" % (n_local, args.mean_bytes),

@@ -13,6 +13,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The built libraries are git-ignored.  In a fresh checkout on a box with the toolchain
+    # (the CPU container), build them once before collection; on the GPU box the prebuilt
+    # files travel with the tree and nothing is built here.
+    import shutil
+    import subprocess
+    hip_so = os.path.join(ROOT, "map_neo_amd", "libmdd_hip.so")
+    if not os.path.exists(hip_so) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "map_neo_amd", "csrc"), "all"])
+    ref_so = os.path.join(ROOT, "oracle", "libmdd_ref.so")
+    if not os.path.exists(ref_so) and shutil.which("gcc"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libmdd_ref.so"])
 
 
 @pytest.fixture(scope="session")

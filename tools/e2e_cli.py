@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the EN drop-in command on synthetic jsonl.gz shards (development
+tool): writes N docs into S shards under a temp dir, runs map_neo_amd.cli.minhashLsh, prints
+where the wall time goes.  The GPU part is a few % -- host JSON/gzip/normalisation dominate."""
+import gzip
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+    shards = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    workers = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    from map_neo_amd import corpus
+    spec = corpus.CorpusSpec(n, 2048, seed=7, lang="en")
+    text, offs = corpus.generate(spec)
+    tb = text.numpy().tobytes()
+    o = offs.numpy()
+    root = tempfile.mkdtemp(prefix="mdd_e2e_")
+    inp = os.path.join(root, "in")
+    os.makedirs(inp)
+    t0 = time.time()
+    per = (n + shards - 1) // shards
+    for s in range(shards):
+        with gzip.open(os.path.join(inp, f"shard-{s:04d}.json.gz"), "wt", encoding="utf8", compresslevel=1) as f:
+            for i in range(s * per, min(n, (s + 1) * per)):
+                f.write(json.dumps({"doc_id": f"shard/{s:04d}/{i:09d}", "raw_content": tb[o[i]:o[i + 1]].decode(), "url": "x"}) + "\n")
+    t_write = time.time() - t0
+    from map_neo_amd.cli import minhashLsh
+    t0 = time.time()
+    stats = minhashLsh.minhashLsh(minhashLsh.build_parser().parse_args(
+        ["--input_dir", inp, "--inter_dir", os.path.join(root, "inter"), "--output_dir", os.path.join(root, "out"),
+         "--workers", str(workers)]))
+    wall = time.time() - t0
+    stats.update({"docs": n, "text_bytes": int(o[-1]), "wall_s": wall, "docs_per_s": n / wall, "shards": shards,
+                  "workers": workers, "make_input_s": t_write})
+    print(json.dumps(stats))
+    shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
