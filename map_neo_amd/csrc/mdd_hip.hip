@@ -292,6 +292,7 @@ struct SigArgs {
     const uint64_t* items;
     const uint64_t* n_items;
     uint64_t max_items;
+    unsigned long long* work_counter;  // zeroed before every launch
     // DUMP mode (mdd_shingle_hashes): one document, hashes written in shingle order
     uint64_t doc_begin, doc_end;
     uint32_t* dump;
@@ -309,13 +310,50 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const uint32_t lane = lane_id();
     WaveLds& lds = lds_all[wave];
 
-    // whole waves exit early below; no workgroup barrier is used anywhere in this kernel
-    uint64_t d = (uint64_t)blockIdx.x * WAVES + wave;
+    const int unit = A.unit;
+    const uint32_t width = (uint32_t)A.width;
+    const uint8_t* text = A.text;
+
+    // ---- permutation constants: lane owns perms q*64 + lane (loaded once per wave)
+    uint32_t alo[KPL], ahi[KPL], blo[KPL], bhi[KPL];
+    if (!DUMP) {
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+            uint32_t pi = q * 64 + lane;
+            uint64_t av = 1, bv = 0;
+            if ((int)pi < A.K) {
+                av = A.a[pi];
+                bv = A.b[pi];
+            }
+            alo[q] = (uint32_t)av;
+            ahi[q] = (uint32_t)(av >> 32);
+            blo[q] = (uint32_t)bv;
+            bhi[q] = (uint32_t)(bv >> 32);
+        }
+    }
+
+    // ---- persistent wave: work items (documents, then queued segments of long documents) are
+    // pulled from one device counter; the next index is fetched before the current item is
+    // processed so the atomic's latency hides behind ~10^5 cycles of hashing.  Every wave
+    // leaves the loop once the counter passes `total`; no workgroup barrier is used anywhere.
+    uint64_t total = 1;
+    if (!DUMP) {
+        uint64_t extra = *A.n_items;  // final: seg_plan_kernel ran before this kernel on the stream
+        total = A.n_docs + (extra < A.max_items ? extra : A.max_items);
+    }
+    auto fetch = [&]() -> uint64_t {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(A.work_counter, 1ull);
+        uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t item = DUMP ? 0 : fetch();
+    while (item < total) {
+    uint64_t next_item = DUMP ? total : fetch();
+    uint64_t d = item;
     uint32_t seg = 0;
     if (!DUMP && d >= A.n_docs) {
-        uint64_t idx = d - A.n_docs;
-        if (idx >= A.max_items || idx >= *A.n_items) return;
-        uint64_t it = A.items[idx];
+        uint64_t it = A.items[d - A.n_docs];
         d = it >> 24;
         seg = (uint32_t)it & 0xFFFFFFu;
     }
@@ -333,30 +371,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const bool split = len > seg_len;  // this wave handles shingles whose first byte lies in [seg_beg, seg_end)
     const uint32_t seg_beg = seg * seg_len;
     const uint32_t seg_end = (uint64_t)seg_beg + seg_len < len ? seg_beg + seg_len : len;
-    const int unit = A.unit;
-    const uint32_t width = (uint32_t)A.width;
-    const uint8_t* text = A.text;
     TextView tv;
     tv.docw = reinterpret_cast<const uint32_t*>(text) + (beg >> 2);
     const uint32_t boff = (uint32_t)beg & 3u;  // byte offset of the document inside docw[0]
-
-    // ---- permutation constants: lane owns perms q*64 + lane
-    uint32_t alo[KPL], ahi[KPL], blo[KPL], bhi[KPL];
-    if (!DUMP) {
-#pragma unroll
-        for (int q = 0; q < KPL; q++) {
-            uint32_t pi = q * 64 + lane;
-            uint64_t av = 1, bv = 0;
-            if ((int)pi < A.K) {
-                av = A.a[pi];
-                bv = A.b[pi];
-            }
-            alo[q] = (uint32_t)av;
-            ahi[q] = (uint32_t)(av >> 32);
-            blo[q] = (uint32_t)bv;
-            bhi[q] = (uint32_t)(bv >> 32);
-        }
-    }
 
     // ---- is the document pure ASCII?  (char unit: boundaries are then implicit)
     bool ascii = false;
@@ -596,6 +613,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             else if (n_sh_total) atomicMin(&A.sig[d * (uint64_t)A.K + pi], m[q]);  // row preset by seg_plan_kernel
         }
     }
+    item = next_item;
+    }  // while (item < total)
 }
 
 // One thread per document: documents longer than seg_bytes get their extra segments queued
@@ -914,12 +933,12 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     c->owns_stream = false;
     c->seg_bytes = SEG_BYTES_DEFAULT;
     c->seg_items = nullptr;
-    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 1) * sizeof(uint64_t));
+    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 2) * sizeof(uint64_t));
     if (me != hipSuccess) {
         delete c;
         return fail(MDD_ERR_HIP, "mdd_ctx_create: hipMalloc of the segment plan failed: %s", hipGetErrorString(me));
     }
-    c->seg_n_items = c->seg_items + SEG_ITEM_CAP;
+    c->seg_n_items = c->seg_items + SEG_ITEM_CAP;  // [0] = queued segments, [1] = work counter of sig_kernel
     *out = c;
     return MDD_OK;
 }
@@ -989,11 +1008,16 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
     A.items = ctx->seg_items;
     A.n_items = ctx->seg_n_items;
     A.max_items = max_items;
-    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, sizeof(uint64_t), ctx->stream));
+    A.work_counter = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 1);
+    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));
     hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, A.seg_bytes,
                        ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, sig_out, K);
     HIP_TRY(hipGetLastError());
-    return launch_sig<false>(ctx, A, grid_for(n_docs + max_items, WAVES));
+    // persistent grid: enough waves to fill every SIMD several times over; surplus waves find the
+    // counter exhausted and leave at once
+    uint64_t waves = (uint64_t)ctx->cus * 4 * 8;
+    if (waves > n_docs + max_items) waves = n_docs + max_items;
+    return launch_sig<false>(ctx, A, grid_for(waves, WAVES));
 }
 
 int mdd_shingle_hashes(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, uint64_t doc_begin, uint64_t doc_end,
