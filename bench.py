@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--mean-bytes", type=int, default=2048)
     ap.add_argument("--cpu-sample-docs", type=int, default=16000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the optional PCIe / pinned-host measurements")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the multi-GPU path (RCCL all-to-all / all-gather) even with one rank")
     args = ap.parse_args()
@@ -155,7 +156,7 @@ def main():
     # PCIe-inclusive figure (reported, never `value`): time one H2D of the packed text from pinned host memory
     h2d_ms = None
     pipelined_sig_ms = None
-    if rank == 0 and world == 1 and text_bytes < (8 << 30):
+    if rank == 0 and world == 1 and text_bytes < (8 << 30) and not args.no_pcie:
         try:
             host = torch.empty(text.numel(), dtype=torch.uint8, pin_memory=True)
             host.copy_(text)
