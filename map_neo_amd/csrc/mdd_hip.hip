@@ -349,271 +349,271 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     };
     uint64_t item = DUMP ? 0 : fetch();
     while (item < total) {
-    uint64_t next_item = DUMP ? total : fetch();
-    uint64_t d = item;
-    uint32_t seg = 0;
-    if (!DUMP && d >= A.n_docs) {
-        uint64_t it = A.items[d - A.n_docs];
-        d = it >> 24;
-        seg = (uint32_t)it & 0xFFFFFFu;
-    }
-
-    uint64_t beg, end;
-    if (DUMP) {
-        beg = A.doc_begin;
-        end = A.doc_end;
-    } else {
-        beg = A.offsets[d];
-        end = A.offsets[d + 1];
-    }
-    const uint32_t len = (uint32_t)(end - beg);
-    const uint32_t seg_len = DUMP ? 0xFFFFFFFFu : A.seg_bytes;
-    const bool split = len > seg_len;  // this wave handles shingles whose first byte lies in [seg_beg, seg_end)
-    const uint32_t seg_beg = seg * seg_len;
-    const uint32_t seg_end = (uint64_t)seg_beg + seg_len < len ? seg_beg + seg_len : len;
-    TextView tv;
-    tv.docw = reinterpret_cast<const uint32_t*>(text) + (beg >> 2);
-    const uint32_t boff = (uint32_t)beg & 3u;  // byte offset of the document inside docw[0]
-
-    // ---- is the document pure ASCII?  (char unit: boundaries are then implicit)
-    bool ascii = false;
-    if (unit == MDD_UNIT_CHAR) {
-        uint32_t acc = 0;
-        if (len) {
-            // bytes the segment's shingles can touch; whole dwords (may include neighbours: conservative)
-            uint32_t hi = (uint64_t)seg_end + width < len ? seg_end + width : len;
-            uint32_t d0 = (boff + seg_beg) >> 2, d1 = (boff + hi - 1u) >> 2;
-            for (uint32_t i = d0 + lane; i <= d1; i += 64) acc |= tv.docw[i];
-        }
-        ascii = __ballot((acc & 0x80808080u) != 0u) == 0ull;
-    }
-
-    uint32_t m[KPL];
-    uint32_t n_sh_total = 0;
-
-    for (int pass = 0; pass < 2; pass++) {
-        const bool exact = pass == 1;  // pass 1 only runs if the fast permute could not prove exactness
-#pragma unroll
-        for (int q = 0; q < KPL; q++) m[q] = 0xFFFFFFFFu;
-
-        // ring state (wave-uniform)
-        uint32_t n_entS = 0, n_entE = 0, pos = seg_beg;
-        bool scan_done = false, seg_done = false;
-        // word unit: a segment that begins inside a token sees that token's END but not its
-        // START; drop that first end so that ringS[k] / ringE[k] keep describing the same token
-        bool skip_end = unit != MDD_UNIT_CHAR && seg_beg > 0 && seg_beg < len && text[beg + seg_beg - 1] != 0x20 &&
-                        text[beg + seg_beg] != 0x20;
-        const uint32_t look = unit == MDD_UNIT_CHAR ? width : width - 1;
-        uint32_t n_done = 0;
-        uint32_t ascii_total = 0;  // shingles of this segment when boundaries are implicit
-        if (ascii && len >= width) {
-            uint32_t j_end = len - width + 1 < seg_end ? len - width + 1 : seg_end;
-            ascii_total = j_end > seg_beg ? j_end - seg_beg : 0;
+        uint64_t next_item = DUMP ? total : fetch();
+        uint64_t d = item;
+        uint32_t seg = 0;
+        if (!DUMP && d >= A.n_docs) {
+            uint64_t it = A.items[d - A.n_docs];
+            d = it >> 24;
+            seg = (uint32_t)it & 0xFFFFFFu;
         }
 
-        for (;;) {
-            uint32_t nvalid;
-            uint32_t s = 0;  // byte offset of the lane's shingle from tv.docw
-            uint32_t L = 0;
-            if (ascii) {
-                uint32_t rest = ascii_total - n_done;
-                nvalid = rest < 64u ? rest : 64u;
-                if (nvalid == 0) break;
-                uint32_t j = seg_beg + n_done + (lane < nvalid ? lane : 0u);
-                s = boff + j;
-                L = width;
-            } else {
-                // ---- fill the boundary ring until a full round is available or the doc ends
-                for (;;) {
-                    uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
-                    if (scan_done || n_ent - n_done >= 64u + look) break;
-                    // window = doc-relative bytes [pos, pos+256); lane handles 4 of them
-                    uint32_t p0 = pos + 4u * lane;
-                    uint32_t fs = 0, fe = 0;
-                    if (unit == MDD_UNIT_CHAR) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            uint32_t p = p0 + k;
-                            if (p < len && (text[beg + p] & 0xC0u) != 0x80u) fs |= 1u << k;
-                        }
-                    } else {
-                        bool prev_sp = (p0 == 0 || p0 > len) ? true : text[beg + p0 - 1] == 0x20;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            uint32_t p = p0 + k;
-                            bool in = p < len;
-                            bool sp = in ? text[beg + p] == 0x20 : true;
-                            bool next_sp = (p + 1 < len) ? text[beg + p + 1] == 0x20 : true;
-                            if (in && !sp && prev_sp) fs |= 1u << k;
-                            if (in && !sp && next_sp) fe |= 1u << k;
-                            prev_sp = sp;
-                        }
-                    }
-                    // ranks in byte order: 4 ballots (one per byte slot)
-                    uint32_t rank_s = 0, tot_s = 0, rank_e = 0, tot_e = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        uint64_t bs = __ballot((fs >> k) & 1u);
-                        rank_s += below(bs);
-                        tot_s += (uint32_t)__popcll(bs);
-                        if (unit != MDD_UNIT_CHAR) {
-                            uint64_t be = __ballot((fe >> k) & 1u);
-                            rank_e += below(be);
-                            tot_e += (uint32_t)__popcll(be);
-                        }
-                    }
-                    uint32_t rs = n_entS + rank_s, re = rank_e;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if ((fs >> k) & 1u) lds.ringS[(rs++) & (RING - 1)] = p0 + k;
-                        if (unit != MDD_UNIT_CHAR && ((fe >> k) & 1u)) {
-                            uint32_t idx = re++;
-                            if (skip_end) {
-                                if (idx == 0) continue;
-                                idx -= 1;
-                            }
-                            lds.ringE[(n_entE + idx) & (RING - 1)] = p0 + k + 1;
-                        }
-                    }
-                    n_entS += tot_s;
-                    if (skip_end && tot_e) {
-                        tot_e -= 1;
-                        skip_end = false;
-                    }
-                    n_entE += tot_e;
-                    pos += 256u;
-                    if (pos >= len) {
-                        scan_done = true;
-                        if (unit == MDD_UNIT_CHAR) {  // sentinel: end of the last code point
-                            if (lane == 0) lds.ringS[n_entS & (RING - 1)] = len;
-                            n_entS += 1;
-                        }
-                    }
-                }
-                wave_sync();
-                uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
-                uint32_t rest = n_ent > n_done + look ? n_ent - look - n_done : 0u;
-                nvalid = rest < 64u ? rest : 64u;
-                if (nvalid == 0 || seg_done) break;
-                uint32_t j = n_done + (lane < nvalid ? lane : 0u);
-                uint32_t sb = lds.ringS[j & (RING - 1)];
-                uint32_t eb = unit == MDD_UNIT_CHAR ? lds.ringS[(j + look) & (RING - 1)]
-                                                    : lds.ringE[(j + look) & (RING - 1)];
-                if (split) {  // units that start at or after seg_end belong to the next segment (starts ascend)
-                    uint32_t nin = (uint32_t)__popcll(__ballot(lane < nvalid && sb < seg_end));
-                    if (nin < nvalid) {
-                        seg_done = true;
-                        nvalid = nin;
-                        if (nvalid == 0) break;
-                        if (lane >= nvalid) {
-                            sb = lds.ringS[n_done & (RING - 1)];
-                            eb = unit == MDD_UNIT_CHAR ? lds.ringS[(n_done + look) & (RING - 1)]
-                                                       : lds.ringE[(n_done + look) & (RING - 1)];
-                        }
-                    }
-                }
-                s = boff + sb;
-                L = eb - sb;
+        uint64_t beg, end;
+        if (DUMP) {
+            beg = A.doc_begin;
+            end = A.doc_end;
+        } else {
+            beg = A.offsets[d];
+            end = A.offsets[d + 1];
+        }
+        const uint32_t len = (uint32_t)(end - beg);
+        const uint32_t seg_len = DUMP ? 0xFFFFFFFFu : A.seg_bytes;
+        const bool split = len > seg_len;  // this wave handles shingles whose first byte lies in [seg_beg, seg_end)
+        const uint32_t seg_beg = seg * seg_len;
+        const uint32_t seg_end = (uint64_t)seg_beg + seg_len < len ? seg_beg + seg_len : len;
+        TextView tv;
+        tv.docw = reinterpret_cast<const uint32_t*>(text) + (beg >> 2);
+        const uint32_t boff = (uint32_t)beg & 3u;  // byte offset of the document inside docw[0]
+
+        // ---- is the document pure ASCII?  (char unit: boundaries are then implicit)
+        bool ascii = false;
+        if (unit == MDD_UNIT_CHAR) {
+            uint32_t acc = 0;
+            if (len) {
+                // bytes the segment's shingles can touch; whole dwords (may include neighbours: conservative)
+                uint32_t hi = (uint64_t)seg_end + width < len ? seg_end + width : len;
+                uint32_t d0 = (boff + seg_beg) >> 2, d1 = (boff + hi - 1u) >> 2;
+                for (uint32_t i = d0 + lane; i <= d1; i += 64) acc |= tv.docw[i];
             }
+            ascii = __ballot((acc & 0x80808080u) != 0u) == 0ull;
+        }
+
+        uint32_t m[KPL];
+        uint32_t n_sh_total = 0;
+
+        for (int pass = 0; pass < 2; pass++) {
+            const bool exact = pass == 1;  // pass 1 only runs if the fast permute could not prove exactness
+#pragma unroll
+            for (int q = 0; q < KPL; q++) m[q] = 0xFFFFFFFFu;
+
+            // ring state (wave-uniform)
+            uint32_t n_entS = 0, n_entE = 0, pos = seg_beg;
+            bool scan_done = false, seg_done = false;
+            // word unit: a segment that begins inside a token sees that token's END but not its
+            // START; drop that first end so that ringS[k] / ringE[k] keep describing the same token
+            bool skip_end = unit != MDD_UNIT_CHAR && seg_beg > 0 && seg_beg < len && text[beg + seg_beg - 1] != 0x20 &&
+                            text[beg + seg_beg] != 0x20;
+            const uint32_t look = unit == MDD_UNIT_CHAR ? width : width - 1;
+            uint32_t n_done = 0;
+            uint32_t ascii_total = 0;  // shingles of this segment when boundaries are implicit
+            if (ascii && len >= width) {
+                uint32_t j_end = len - width + 1 < seg_end ? len - width + 1 : seg_end;
+                ascii_total = j_end > seg_beg ? j_end - seg_beg : 0;
+            }
+
+            for (;;) {
+                uint32_t nvalid;
+                uint32_t s = 0;  // byte offset of the lane's shingle from tv.docw
+                uint32_t L = 0;
+                if (ascii) {
+                    uint32_t rest = ascii_total - n_done;
+                    nvalid = rest < 64u ? rest : 64u;
+                    if (nvalid == 0) break;
+                    uint32_t j = seg_beg + n_done + (lane < nvalid ? lane : 0u);
+                    s = boff + j;
+                    L = width;
+                } else {
+                    // ---- fill the boundary ring until a full round is available or the doc ends
+                    for (;;) {
+                        uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
+                        if (scan_done || n_ent - n_done >= 64u + look) break;
+                        // window = doc-relative bytes [pos, pos+256); lane handles 4 of them
+                        uint32_t p0 = pos + 4u * lane;
+                        uint32_t fs = 0, fe = 0;
+                        if (unit == MDD_UNIT_CHAR) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                uint32_t p = p0 + k;
+                                if (p < len && (text[beg + p] & 0xC0u) != 0x80u) fs |= 1u << k;
+                            }
+                        } else {
+                            bool prev_sp = (p0 == 0 || p0 > len) ? true : text[beg + p0 - 1] == 0x20;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                uint32_t p = p0 + k;
+                                bool in = p < len;
+                                bool sp = in ? text[beg + p] == 0x20 : true;
+                                bool next_sp = (p + 1 < len) ? text[beg + p + 1] == 0x20 : true;
+                                if (in && !sp && prev_sp) fs |= 1u << k;
+                                if (in && !sp && next_sp) fe |= 1u << k;
+                                prev_sp = sp;
+                            }
+                        }
+                        // ranks in byte order: 4 ballots (one per byte slot)
+                        uint32_t rank_s = 0, tot_s = 0, rank_e = 0, tot_e = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint64_t bs = __ballot((fs >> k) & 1u);
+                            rank_s += below(bs);
+                            tot_s += (uint32_t)__popcll(bs);
+                            if (unit != MDD_UNIT_CHAR) {
+                                uint64_t be = __ballot((fe >> k) & 1u);
+                                rank_e += below(be);
+                                tot_e += (uint32_t)__popcll(be);
+                            }
+                        }
+                        uint32_t rs = n_entS + rank_s, re = rank_e;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if ((fs >> k) & 1u) lds.ringS[(rs++) & (RING - 1)] = p0 + k;
+                            if (unit != MDD_UNIT_CHAR && ((fe >> k) & 1u)) {
+                                uint32_t idx = re++;
+                                if (skip_end) {
+                                    if (idx == 0) continue;
+                                    idx -= 1;
+                                }
+                                lds.ringE[(n_entE + idx) & (RING - 1)] = p0 + k + 1;
+                            }
+                        }
+                        n_entS += tot_s;
+                        if (skip_end && tot_e) {
+                            tot_e -= 1;
+                            skip_end = false;
+                        }
+                        n_entE += tot_e;
+                        pos += 256u;
+                        if (pos >= len) {
+                            scan_done = true;
+                            if (unit == MDD_UNIT_CHAR) {  // sentinel: end of the last code point
+                                if (lane == 0) lds.ringS[n_entS & (RING - 1)] = len;
+                                n_entS += 1;
+                            }
+                        }
+                    }
+                    wave_sync();
+                    uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
+                    uint32_t rest = n_ent > n_done + look ? n_ent - look - n_done : 0u;
+                    nvalid = rest < 64u ? rest : 64u;
+                    if (nvalid == 0 || seg_done) break;
+                    uint32_t j = n_done + (lane < nvalid ? lane : 0u);
+                    uint32_t sb = lds.ringS[j & (RING - 1)];
+                    uint32_t eb = unit == MDD_UNIT_CHAR ? lds.ringS[(j + look) & (RING - 1)]
+                                                        : lds.ringE[(j + look) & (RING - 1)];
+                    if (split) {  // units that start at or after seg_end belong to the next segment (starts ascend)
+                        uint32_t nin = (uint32_t)__popcll(__ballot(lane < nvalid && sb < seg_end));
+                        if (nin < nvalid) {
+                            seg_done = true;
+                            nvalid = nin;
+                            if (nvalid == 0) break;
+                            if (lane >= nvalid) {
+                                sb = lds.ringS[n_done & (RING - 1)];
+                                eb = unit == MDD_UNIT_CHAR ? lds.ringS[(n_done + look) & (RING - 1)]
+                                                           : lds.ringE[(n_done + look) & (RING - 1)];
+                            }
+                        }
+                    }
+                    s = boff + sb;
+                    L = eb - sb;
+                }
 
 #ifdef MDD_DBG_NOSHA   // development ablation only (tools/sig_bench.hip); never defined in the library build
-            uint32_t h = s * 2654435761u + L;
+                uint32_t h = s * 2654435761u + L;
 #else
-            uint32_t Lmax = ascii ? width : uni(wave_max(L));
-            uint32_t h = hash_any(tv, s, L, Lmax, ascii && width == 13u);
+                uint32_t Lmax = ascii ? width : uni(wave_max(L));
+                uint32_t h = hash_any(tv, s, L, Lmax, ascii && width == 13u);
 #endif
 
-            if (DUMP) {
-                uint64_t o = (uint64_t)n_done + lane;
-                if (lane < nvalid && o < A.dump_cap) A.dump[o] = h;
-            } else {
-                // lanes >= nvalid duplicate lane 0's shingle: harmless for a min
-                wave_sync();
-                lds.hbuf[lane] = h;
-                wave_sync();
+                if (DUMP) {
+                    uint64_t o = (uint64_t)n_done + lane;
+                    if (lane < nvalid && o < A.dump_cap) A.dump[o] = h;
+                } else {
+                    // lanes >= nvalid duplicate lane 0's shingle: harmless for a min
+                    wave_sync();
+                    lds.hbuf[lane] = h;
+                    wave_sync();
 #ifdef MDD_DBG_PERM1
-                const uint32_t n4 = 1;
+                    const uint32_t n4 = 1;
 #else
-                const uint32_t n4 = uni((nvalid + 3u) >> 2);
+                    const uint32_t n4 = uni((nvalid + 3u) >> 2);
 #endif
-                const uint4* hb4 = reinterpret_cast<const uint4*>(lds.hbuf);
+                    const uint4* hb4 = reinterpret_cast<const uint4*>(lds.hbuf);
 #ifdef MDD_DBG_NOPERM
-                m[0] ^= hb4[lane & 15].x;
-                if (false) {
+                    m[0] ^= hb4[lane & 15].x;
+                    if (false) {
 #else
-                if (!exact) {
+                    if (!exact) {
 #endif
-                    // fast form: t' = a*h + (b+1) mod 2^64 ; s = lo32(t') + (t' >> 61).
-                    // If s > 8 then s - 1 is exactly ((a*h+b) mod 2^64) mod (2^61-1) & 0xFFFFFFFF
-                    // (proof in DESIGN.md); a minimum <= 8 sends the document to the exact pass.
-                    for (uint32_t i = 0; i < n4; i++) {
-                        uint4 hv = hb4[i];
-                        uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
+                        // fast form: t' = a*h + (b+1) mod 2^64 ; s = lo32(t') + (t' >> 61).
+                        // If s > 8 then s - 1 is exactly ((a*h+b) mod 2^64) mod (2^61-1) & 0xFFFFFFFF
+                        // (proof in DESIGN.md); a minimum <= 8 sends the document to the exact pass.
+                        for (uint32_t i = 0; i < n4; i++) {
+                            uint4 hv = hb4[i];
+                            uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
+                            for (int e = 0; e < 4; e++) {
 #pragma unroll
-                            for (int q = 0; q < KPL; q++) {
-                                uint64_t b1 = (((uint64_t)bhi[q] << 32) | blo[q]) + 1ull;
-                                uint64_t t = (uint64_t)alo[q] * hh[e] + b1;
-                                // hipcc fuses this into a second v_mad_u64_u32 (+ v_mov).  Measured
-                                // alternatives, both slower: v_mul_lo_u32 + v_add_u32 (-7 %), and
-                                // pre-adding a_hi*h into the high half of the first mad's addend
-                                // (hipcc turns it into mad + mov + v_lshl_add_u64).
-                                uint32_t thi = (uint32_t)(t >> 32) + ahi[q] * hh[e];
-                                uint32_t sv = (uint32_t)t + (thi >> 29);
-                                m[q] = sv < m[q] ? sv : m[q];
+                                for (int q = 0; q < KPL; q++) {
+                                    uint64_t b1 = (((uint64_t)bhi[q] << 32) | blo[q]) + 1ull;
+                                    uint64_t t = (uint64_t)alo[q] * hh[e] + b1;
+                                    // hipcc fuses this into a second v_mad_u64_u32 (+ v_mov).  Measured
+                                    // alternatives, both slower: v_mul_lo_u32 + v_add_u32 (-7 %), and
+                                    // pre-adding a_hi*h into the high half of the first mad's addend
+                                    // (hipcc turns it into mad + mov + v_lshl_add_u64).
+                                    uint32_t thi = (uint32_t)(t >> 32) + ahi[q] * hh[e];
+                                    uint32_t sv = (uint32_t)t + (thi >> 29);
+                                    m[q] = sv < m[q] ? sv : m[q];
+                                }
                             }
                         }
-                    }
-                } else {
-                    for (uint32_t i = 0; i < n4; i++) {
-                        uint4 hv = hb4[i];
-                        uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
+                    } else {
+                        for (uint32_t i = 0; i < n4; i++) {
+                            uint4 hv = hb4[i];
+                            uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
+                            for (int e = 0; e < 4; e++) {
 #pragma unroll
-                            for (int q = 0; q < KPL; q++) {
-                                uint64_t av = ((uint64_t)ahi[q] << 32) | alo[q];
-                                uint64_t bv = ((uint64_t)bhi[q] << 32) | blo[q];
-                                uint64_t t = av * (uint64_t)hh[e] + bv;  // wraps mod 2^64 like numpy uint64
-                                uint64_t x = (t & P61) + (t >> 61);
-                                if (x >= P61) x -= P61;
-                                uint32_t r = (uint32_t)x;
-                                m[q] = r < m[q] ? r : m[q];
+                                for (int q = 0; q < KPL; q++) {
+                                    uint64_t av = ((uint64_t)ahi[q] << 32) | alo[q];
+                                    uint64_t bv = ((uint64_t)bhi[q] << 32) | blo[q];
+                                    uint64_t t = av * (uint64_t)hh[e] + bv;  // wraps mod 2^64 like numpy uint64
+                                    uint64_t x = (t & P61) + (t >> 61);
+                                    if (x >= P61) x -= P61;
+                                    uint32_t r = (uint32_t)x;
+                                    m[q] = r < m[q] ? r : m[q];
+                                }
                             }
                         }
                     }
                 }
+                n_done += nvalid;
             }
-            n_done += nvalid;
-        }
-        n_sh_total = n_done;
+            n_sh_total = n_done;
 
-        if (DUMP) break;
-        if (exact) break;
-        bool risky = false;
+            if (DUMP) break;
+            if (exact) break;
+            bool risky = false;
 #pragma unroll
-        for (int q = 0; q < KPL; q++) risky |= (m[q] <= FAST_GUARD);
-        if (n_sh_total == 0 || __ballot(risky) == 0ull) {
+            for (int q = 0; q < KPL; q++) risky |= (m[q] <= FAST_GUARD);
+            if (n_sh_total == 0 || __ballot(risky) == 0ull) {
 #pragma unroll
-            for (int q = 0; q < KPL; q++) m[q] = n_sh_total ? m[q] - 1u : 0xFFFFFFFFu;
-            break;
+                for (int q = 0; q < KPL; q++) m[q] = n_sh_total ? m[q] - 1u : 0xFFFFFFFFu;
+                break;
+            }
         }
-    }
 
-    if (DUMP) {
-        if (lane == 0 && wave == 0 && blockIdx.x == 0) *A.dump_n = n_sh_total;
-        return;
-    }
-#pragma unroll
-    for (int q = 0; q < KPL; q++) {
-        uint32_t pi = q * 64 + lane;
-        if ((int)pi < A.K) {
-            if (!split) A.sig[d * (uint64_t)A.K + pi] = m[q];
-            else if (n_sh_total) atomicMin(&A.sig[d * (uint64_t)A.K + pi], m[q]);  // row preset by seg_plan_kernel
+        if (DUMP) {
+            if (lane == 0 && wave == 0 && blockIdx.x == 0) *A.dump_n = n_sh_total;
+            return;
         }
-    }
-    item = next_item;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+            uint32_t pi = q * 64 + lane;
+            if ((int)pi < A.K) {
+                if (!split) A.sig[d * (uint64_t)A.K + pi] = m[q];
+                else if (n_sh_total) atomicMin(&A.sig[d * (uint64_t)A.K + pi], m[q]);  // row preset by seg_plan_kernel
+            }
+        }
+        item = next_item;
     }  // while (item < total)
 }
 
