@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Stage entry point with the I/O contract of BASELINE.json's north_star: jsonl / jsonl.gz /
+parquet shards in, kept-document ids and cluster assignments out.
+
+    python -m map_neo_amd.cli.dedup --input_dir I --output_dir O \
+        [--id_field doc_id] [--content_field raw_content] [--normalize en|none] [--write_shards]
+
+Outputs in O:
+  kept_ids.txt / removed_ids.txt   one document id per line
+  clusters.jsonl                   {"doc_id": ..., "cluster": <id of the surviving member>} for every
+                                   document of a cluster with more than one member
+  summary.json                     counts and timings
+  shards/<name>.jsonl.gz           (with --write_shards) the surviving rows of every input shard
+Documents without an id field get "<file>@<row>" (the ZH convention, ZH-1:45).  Rows whose
+content is null / missing / not utf-8 encodable are never hashed and always kept (EN:124,
+ZH-1:52-54).  --normalize en applies EN:31-40 before hashing (the EN pipeline), none hashes
+the raw field (the ZH pipeline).  The survivor of a cluster is its smallest id when ids come
+from the data (EN:145) and its first document in input order otherwise.
+LSH parameters default to the reference's constants (EN:17-20 / ZH-1:14-17).
+"""
+from __future__ import annotations
+
+import argparse
+import gzip
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    p.add_argument("--input_dir", required=True)
+    p.add_argument("--output_dir", required=True)
+    p.add_argument("--id_field", default="doc_id")
+    p.add_argument("--content_field", default="raw_content")
+    p.add_argument("--normalize", choices=["en", "none"], default="en")
+    p.add_argument("--write_shards", action="store_true")
+    p.add_argument("--width", type=int, default=13)
+    p.add_argument("--ngram_unit", choices=["char", "word"], default="char")
+    p.add_argument("--num_perm", type=int, default=128)
+    p.add_argument("--bands", type=int, default=9)
+    p.add_argument("--rows", type=int, default=13)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
+    return p
+
+
+def _parse_shard(task):
+    path, id_field, content_field, normalize = task
+    from .. import hostio
+    name = os.path.basename(path)
+    ids, cand, enc, synthetic = [], [], [], False
+    for k, row in enumerate(hostio.iter_records(path, [id_field, content_field])):
+        rid = row.get(id_field) if isinstance(row, dict) else None
+        if rid is None:
+            rid, synthetic = f"{name}@{k}", True
+        text = row.get(content_field) if isinstance(row, dict) else None
+        if isinstance(text, str) and hostio.encodable(text):
+            cand.append(len(ids))
+            enc.append((hostio.normalize_text(text) if normalize == "en" else text).encode("utf8"))
+        ids.append(rid)
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+    return ids, np.asarray(cand, dtype=np.int64), np.frombuffer(b"".join(enc), dtype=np.uint8), offs, synthetic
+
+
+def _write_shard(task):
+    path, out_path, id_field, remove_ids = task
+    from .. import hostio
+    name = os.path.basename(path)
+    kept = 0
+    with gzip.open(out_path, "wt", encoding="utf8") as f:
+        for k, row in enumerate(hostio.iter_records(path)):
+            if not isinstance(row, dict):
+                continue
+            rid = row.get(id_field)
+            if rid is None:
+                rid = f"{name}@{k}"
+            if rid not in remove_ids:
+                f.write(json.dumps(row, ensure_ascii=False, default=str) + "\n")
+                kept += 1
+    return kept
+
+
+def run(args) -> dict:
+    from .. import hostio
+    files = hostio.list_files(args.input_dir)
+    os.makedirs(args.output_dir, exist_ok=True)
+    t0 = time.time()
+    pool = mp.get_context("fork").Pool(max(1, args.workers))      # forked before this process touches the GPU
+    try:
+        parsed = pool.imap(_parse_shard, [(p, args.id_field, args.content_field, args.normalize) for p in files])
+        import torch
+
+        from ..dedup import cluster_local
+        from ..minhash import Engine, as_u32, padded_size
+        eng = Engine(args.device)
+        sigs, all_ids, cand_ids, any_synth = [], [], [], False
+        for ids, cand, text, offs, synthetic in parsed:
+            any_synth |= synthetic
+            all_ids.extend(ids)
+            if len(cand):
+                buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+                buf[: text.size] = text
+                sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                                           args.ngram_unit, args.seed, text_bytes=int(text.size)))
+                cand_ids.extend(ids[i] for i in cand.tolist())
+        t1 = time.time()
+        n = len(cand_ids)
+        sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
+        out = cluster_local(eng, sig, args.bands, args.rows)
+        labels = as_u32(out["labels"])
+        members = np.flatnonzero(labels != np.arange(n, dtype=np.uint32))
+        clustered = sorted(set(members.tolist()) | set(labels[members].tolist()))
+        # representative: smallest id (EN:145) unless ids were synthesised, then first in input order
+        rep = {}
+        for k in clustered:
+            l = int(labels[k])
+            if l not in rep or (not any_synth and cand_ids[k] < rep[l]):
+                rep[l] = cand_ids[k]
+        remove_ids = {cand_ids[k] for k in clustered if cand_ids[k] != rep[int(labels[k])]}
+        t2 = time.time()
+        with open(os.path.join(args.output_dir, "clusters.jsonl"), "w", encoding="utf8") as f:
+            for k in clustered:
+                f.write(json.dumps({"doc_id": cand_ids[k], "cluster": rep[int(labels[k])]}, ensure_ascii=False) + "\n")
+        with open(os.path.join(args.output_dir, "removed_ids.txt"), "w", encoding="utf8") as fr, \
+                open(os.path.join(args.output_dir, "kept_ids.txt"), "w", encoding="utf8") as fk:
+            for d in all_ids:
+                (fr if d in remove_ids else fk).write(f"{d}\n")
+        kept_rows = None
+        if args.write_shards:
+            os.makedirs(os.path.join(args.output_dir, "shards"), exist_ok=True)
+            tasks = [(p, os.path.join(args.output_dir, "shards", os.path.basename(p).split(".")[0] + ".jsonl.gz"),
+                      args.id_field, remove_ids) for p in files]
+            kept_rows = sum(pool.imap_unordered(_write_shard, tasks))
+        t3 = time.time()
+    finally:
+        pool.close()
+        pool.join()
+    summary = {"n_rows": len(all_ids), "n_hashed": n, "n_removed_ids": len(remove_ids),
+               "n_clusters": len(rep), "n_clustered_docs": len(clustered), "kept_rows_written": kept_rows,
+               "t_parse_signatures_s": t1 - t0, "t_cluster_s": t2 - t1, "t_write_s": t3 - t2}
+    with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
+        json.dump(summary, f)
+    print(json.dumps(summary), file=sys.stderr)
+    return summary
+
+
+def main(argv=None):
+    run(build_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

@@ -60,3 +60,27 @@ def encodable(text: str) -> bool:
         return True
     except UnicodeEncodeError:
         return False
+
+
+def iter_records(path: str, fields=None):
+    """Rows of one shard as dicts: JSON-lines (optionally .gz) or Parquet (.parquet / .pq, via
+    pyarrow; `fields` restricts the columns read).  Blank JSON lines are skipped; a JSON line
+    that does not parse is yielded as None so that the caller can count/skip it while keeping
+    line numbers aligned with the file."""
+    low = path.lower()
+    if low.endswith((".parquet", ".pq")):
+        import pyarrow.parquet as pq
+        pf = pq.ParquetFile(path)
+        cols = [c for c in fields if c in pf.schema_arrow.names] if fields else None
+        for batch in pf.iter_batches(batch_size=65536, columns=cols):
+            for row in batch.to_pylist():
+                yield row
+        return
+    import json
+    for line in iter_lines(path):
+        if not line.strip():
+            continue
+        try:
+            yield json.loads(line)
+        except ValueError:
+            yield None

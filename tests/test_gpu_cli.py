@@ -136,3 +136,46 @@ def test_en_cli_duplicate_doc_ids(tmp_path, mini_docs, capsys):
     # component {a, b, c} keeps the smallest id "a" (both of its rows); "d" is untouched
     assert sorted(r["doc_id"] for r in out_rows) == ["a", "a", "d"]
     assert "the number of doc need to be remove is  2" in capsys.readouterr().out
+
+
+def test_stage_entry_point_jsonl_and_parquet(tmp_path, mini_docs):
+    """north_star I/O contract: jsonl / parquet shards in, kept ids + cluster assignments out"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from map_neo_amd.cli import dedup as stage
+    n = len(mini_docs)
+    ids = [f"id{(i * 37) % n:04d}" for i in range(n)]
+    inp = tmp_path / "in"
+    inp.mkdir()
+    with open(inp / "a.jsonl", "w", encoding="utf8") as f:
+        for i in range(0, 60):
+            f.write(json.dumps({"doc_id": ids[i], "raw_content": mini_docs[i]}, ensure_ascii=False) + "\n")
+    with gzip.open(inp / "b.jsonl.gz", "wt", encoding="utf8") as f:
+        for i in range(60, 120):
+            f.write(json.dumps({"doc_id": ids[i], "raw_content": mini_docs[i]}, ensure_ascii=False) + "\n")
+    pq.write_table(pa.table({"doc_id": ids[120:], "raw_content": mini_docs[120:], "extra": list(range(120, n))}),
+                   inp / "c.parquet")
+    out = tmp_path / "out"
+    s = stage.run(stage.build_parser().parse_args(["--input_dir", str(inp), "--output_dir", str(out), "--normalize", "none",
+                                                   "--write_shards", "--workers", "2"]))
+    exp = R.dedup(mini_docs)
+    lab = exp["labels"]
+    comp = {}
+    for k in range(n):
+        comp.setdefault(int(lab[k]), []).append(k)
+    exp_removed, exp_cluster = set(), {}
+    for members in comp.values():
+        if len(members) > 1:
+            keep = min(ids[k] for k in members)
+            for k in members:
+                exp_cluster[ids[k]] = keep
+                if ids[k] != keep:
+                    exp_removed.add(ids[k])
+    assert set(open(out / "removed_ids.txt").read().split()) == exp_removed
+    assert set(open(out / "kept_ids.txt").read().split()) == set(ids) - exp_removed
+    got_cluster = {r["doc_id"]: r["cluster"] for r in map(json.loads, open(out / "clusters.jsonl", encoding="utf8"))}
+    assert got_cluster == exp_cluster
+    assert s["n_removed_ids"] == len(exp_removed) and s["kept_rows_written"] == n - len(exp_removed)
+    rows = [json.loads(l) for p in sorted(os.listdir(out / "shards")) for l in gzip.open(out / "shards" / p, "rt", encoding="utf8")]
+    assert {r["doc_id"] for r in rows} == set(ids) - exp_removed
+    assert any("extra" in r for r in rows)
