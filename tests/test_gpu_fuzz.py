@@ -1,0 +1,60 @@
+"""GPU suite: seeded random sweep over (K, width, unit, bands, rows, segment length) and random
+utf-8 documents; signatures and component labels must equal the C oracle bit for bit."""
+import numpy as np
+import pytest
+
+from map_neo_amd.dedup import dedup_local
+from map_neo_amd.minhash import as_u32, pack_texts
+from oracle import ref_c as RC
+
+pytestmark = pytest.mark.gpu
+
+POOLS = [(0x20, 0x7F), (0x80, 0x7FF), (0x800, 0xD7FF), (0xE000, 0xFFFF), (0x10000, 0x10FFFF)]
+
+
+def _docs(rng, n):
+    base = []
+    for _ in range(n):
+        kind = rng.integers(0, 4)
+        ln = int(rng.integers(0, 600)) if rng.random() < 0.8 else int(rng.integers(0, 20))
+        if kind == 0:
+            cps = rng.integers(0x61, 0x7B, ln)
+            cps[rng.random(ln) < 0.18] = 0x20                       # words separated by (runs of) spaces
+        elif kind == 1:
+            cps = rng.integers(0x4E00, 0x9FFF, ln)
+        else:
+            pools = rng.integers(0, len(POOLS), ln)
+            cps = np.array([rng.integers(*POOLS[p]) for p in pools], dtype=np.int64)
+            cps[rng.random(ln) < 0.1] = 0x20
+        base.append("".join(chr(int(c)) for c in cps))
+    docs = list(base)
+    for _ in range(n // 3):                                         # near / exact copies so that clusters exist
+        t = base[int(rng.integers(0, n))]
+        if len(t) > 30 and rng.random() < 0.7:
+            k = int(rng.integers(0, len(t) - 1))
+            t = t[:k] + "Z" + t[k + 1:]
+        docs.append(t)
+    return docs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations(engine, seed):
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    docs = _docs(rng, 150)
+    K = int(rng.choice([1, 7, 64, 65, 100, 128, 129, 192, 200, 256]))
+    unit = "char" if rng.random() < 0.6 else "word"
+    width = int(rng.integers(1, 41)) if unit == "char" else int(rng.integers(1, 9))
+    rows = int(rng.integers(1, min(K, 16) + 1))
+    bands = int(rng.integers(1, min(64, K // rows) + 1))
+    seg = int(rng.choice([0, 256, 768]))
+    sd = int(rng.integers(0, 1 << 31))
+    buf, offs = pack_texts(docs)
+    engine.set_segment_bytes(seg)
+    try:
+        out = dedup_local(engine, engine.to_device(buf), engine.to_device(offs), K, width, unit, bands, rows, seed=sd)
+    finally:
+        engine.set_segment_bytes(0)
+    exp_sig = RC.signatures(buf, offs, K, width, unit, seed=sd)
+    assert (as_u32(out["sig"]).reshape(len(docs), K) == exp_sig).all(), (K, unit, width, seg)
+    exp_labels, _ = RC.cluster(exp_sig, bands, rows)
+    assert (as_u32(out["labels"]) == exp_labels).all(), (K, bands, rows)
