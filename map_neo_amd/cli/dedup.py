@@ -54,6 +54,13 @@ def _parse_shard(task):
     path, id_field, content_field, normalize = task
     from .. import hostio
     name = os.path.basename(path)
+    if not path.lower().endswith((".parquet", ".pq")):
+        r = hostio.read_jsonl_shard(path, content_field, id_field, normalize_en=(normalize == "en"), on_error="skip")
+        ids, synthetic = r["ids"], False
+        for k, rid in enumerate(ids):
+            if rid is None:
+                ids[k], synthetic = f"{name}@{int(r['line_no'][k])}", True
+        return ids, r["cand"], r["text"], r["offsets"], synthetic
     ids, cand, enc, synthetic = [], [], [], False
     for k, row in enumerate(hostio.iter_records(path, [id_field, content_field])):
         rid = row.get(id_field) if isinstance(row, dict) else None
@@ -70,18 +77,28 @@ def _parse_shard(task):
     return ids, np.asarray(cand, dtype=np.int64), np.frombuffer(b"".join(enc), dtype=np.uint8), offs, synthetic
 
 
+def _loads_or_none(line):
+    try:
+        return json.loads(line)
+    except ValueError:
+        return None
+
+
 def _write_shard(task):
     path, out_path, id_field, remove_ids = task
     from .. import hostio
     name = os.path.basename(path)
     kept = 0
-    with gzip.open(out_path, "wt", encoding="utf8") as f:
-        for k, row in enumerate(hostio.iter_records(path)):
+    is_pq = path.lower().endswith((".parquet", ".pq"))
+    rows = enumerate(hostio.iter_records(path)) if is_pq else \
+        ((k, _loads_or_none(line)) for k, line in enumerate(hostio.iter_lines(path)) if line.strip())
+    with gzip.open(out_path, "wt", encoding="utf8", compresslevel=6) as f:
+        for k, row in rows:
             if not isinstance(row, dict):
                 continue
             rid = row.get(id_field)
             if rid is None:
-                rid = f"{name}@{k}"
+                rid = f"{name}@{k}"                       # k = physical line number (jsonl) / row number (parquet)
             if rid not in remove_ids:
                 f.write(json.dumps(row, ensure_ascii=False, default=str) + "\n")
                 kept += 1

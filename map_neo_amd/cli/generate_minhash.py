@@ -32,7 +32,7 @@ def build_parser():
 
 def process_dir(args):
     from .. import hostio
-    from ..minhash import Engine, as_u32, pack_texts
+    from ..minhash import Engine, as_u32, padded_size
     eng = Engine(args.device)
     os.makedirs(args.output_dir, exist_ok=True)
     for band in range(args.bands):
@@ -40,12 +40,13 @@ def process_dir(args):
     for path in hostio.list_files(args.input_dir):
         name = os.path.basename(path)
         print(f"process file {name}")
-        docs = Z.read_jsonl_texts(path, args.content_field_name)     # no normalisation in the ZH path (ZH-1:46)
-        buf, offs = pack_texts([t for _, t in docs])
+        line_no, text, offs = Z.read_jsonl_texts(path, args.content_field_name)     # no normalisation in the ZH path (ZH-1:46)
+        buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+        buf[: text.size] = text
         sig = as_u32(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
-                                    args.ngram_unit, args.seed, text_bytes=int(offs[-1])))
-        sig = sig.reshape(len(docs), args.num_perm)
-        ids = [f"{name}@{idx}" for idx, _ in docs]
+                                    args.ngram_unit, args.seed, text_bytes=int(text.size)))
+        sig = sig.reshape(len(line_no), args.num_perm)
+        ids = [f"{name}@{idx}" for idx in line_no.tolist()]
         for band in range(args.bands):
             keys = Z.band_key_bytes(sig, band, args.rows)
             recs = [{"doc_id": d, "hash": k} for d, k in zip(ids, keys)]

@@ -56,23 +56,14 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def _parse_file(task):
-    """pool worker, pass 1: (doc_ids of all rows, indices of candidate rows, packed text, offsets)"""
+    """pool worker, pass 1: (doc_ids of all rows, indices of candidate rows, packed text, offsets).
+    Native scanner + ASCII normaliser where it is sure, the Python steps elsewhere (hostio)."""
     path, field = task
     from .. import hostio
-    ids, cand, enc = [], [], []
-    for line in hostio.iter_lines(path):
-        if not line.strip():
-            continue
-        row = json.loads(line)
-        text = row.get(field)
-        if text is not None and hostio.encodable(text):        # EN:124 null filter; un-encodable text is skipped
-            cand.append(len(ids))
-            enc.append(hostio.normalize_text(text).encode("utf8"))
-        ids.append(row.get("doc_id"))
-    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
-    if enc:
-        offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
-    return path, ids, np.asarray(cand, dtype=np.int64), np.frombuffer(b"".join(enc), dtype=np.uint8), offs
+    r = hostio.read_jsonl_shard(path, field, "doc_id", normalize_en=True, on_error="skip")
+    if r["n_bad"]:
+        print(f"{os.path.basename(path)}: {r['n_bad']} lines are not JSON objects and were skipped", file=sys.stderr)
+    return path, r["ids"], r["cand"], r["text"], r["offsets"]
 
 
 def _write_file(task):
@@ -80,11 +71,16 @@ def _write_file(task):
     path, out_path, remove_ids = task
     from .. import hostio
     kept = 0
-    with gzip.open(out_path, "wt", encoding="utf8") as f:
+    with gzip.open(out_path, "wt", encoding="utf8", compresslevel=6) as f:      # zlib's default level, as Spark's gzip codec
         for line in hostio.iter_lines(path):
             if not line.strip():
                 continue
-            row = json.loads(line)
+            try:
+                row = json.loads(line)
+            except ValueError:
+                continue
+            if not isinstance(row, dict):
+                continue
             if row.get("doc_id") not in remove_ids:
                 f.write(json.dumps(row, ensure_ascii=False) + "\n")
                 kept += 1

@@ -26,20 +26,13 @@ def natural_key(doc_id: str) -> Tuple[str, int]:
 
 
 def read_jsonl_texts(path: str, field: str):
-    """(line_idx, text) for every line that parses, has the field and can be utf-8 encoded;
-    failures are reported and skipped like ZH-1:43-54 (skipped lines are never removed)."""
-    name = os.path.basename(path)
-    out = []
-    for idx, line in enumerate(hostio.iter_lines(path)):
-        try:
-            text = json.loads(line)[field]
-            if not isinstance(text, str):
-                raise TypeError(f"field {field!r} is not a string")
-            text.encode("utf8")
-            out.append((idx, text))
-        except Exception as e:  # noqa: BLE001 -- mirror of the reference's catch-all
-            print(f"procces file {name} line {idx} error happe: {e}")
-    return out
+    """(line_idx, text bytes) for every line that parses, has a string in `field` and can be utf-8
+    encoded; other lines are skipped like ZH-1:43-54 (skipped lines are never removed).  Returns
+    (line numbers uint64 [n], packed text uint8, offsets uint64 [n+1])."""
+    r = hostio.read_jsonl_shard(path, field, None, normalize_en=False, on_error="skip")
+    if r["n_bad"]:
+        print(f"procces file {os.path.basename(path)}: {r['n_bad']} lines skipped (not JSON objects)")
+    return r["line_no"][r["cand"]], r["text"], r["offsets"]
 
 
 def band_key_bytes(sig_u32: np.ndarray, band: int, rows: int) -> List[bytes]:

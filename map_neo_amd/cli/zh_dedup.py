@@ -34,19 +34,23 @@ def build_parser():
 
 def run(args):
     from .. import hostio
-    from ..dedup import dedup_local
-    from ..minhash import Engine, as_u32, pack_texts
+    from ..dedup import cluster_local
+    from ..minhash import Engine, as_u32, padded_size
     files = hostio.list_files(args.input_dir)
-    ids, texts = [], []
-    for path in files:
-        name = os.path.basename(path)
-        for idx, text in Z.read_jsonl_texts(path, args.content_field_name):
-            ids.append((name, idx))
-            texts.append(text)
+    import torch
     eng = Engine(args.device)
-    buf, offs = pack_texts(texts)
-    out = dedup_local(eng, eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width, args.ngram_unit,
-                      args.bands, args.rows, args.seed, text_bytes=int(offs[-1]))
+    ids, sigs = [], []
+    for path in files:                                   # one shard at a time: signatures stay in HBM, text does not
+        name = os.path.basename(path)
+        line_no, text, offs = Z.read_jsonl_texts(path, args.content_field_name)
+        ids.extend((name, int(i)) for i in line_no.tolist())
+        if len(line_no):
+            buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+            buf[: text.size] = text
+            sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                                       args.ngram_unit, args.seed, text_bytes=int(text.size)))
+    sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
+    out = cluster_local(eng, sig, args.bands, args.rows)
     labels = as_u32(out["labels"])
     removed = labels != np.arange(len(ids), dtype=np.uint32)
     drop = {}

@@ -84,3 +84,172 @@ def iter_records(path: str, fields=None):
             yield json.loads(line)
         except ValueError:
             yield None
+
+
+# ------------------------------------------------------------------------------------------
+# native JSON-lines ingest (libmdd_io.so, include/mdd_io.h) with per-line Python fallback
+# ------------------------------------------------------------------------------------------
+_IO_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdd_io.so")
+_io_lib = None
+
+
+def _io():
+    """libmdd_io.so or None (the pure-Python path is always available and equivalent)."""
+    global _io_lib
+    if _io_lib is None:
+        import ctypes as C
+        if not os.path.exists(_IO_SO):
+            _io_lib = False
+            return None
+        L = C.CDLL(_IO_SO)
+        L.mdd_io_read_jsonl.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mdd_io_read_jsonl.restype = C.c_int
+        L.mdd_io_free.argtypes = [C.c_void_p]
+        L.mdd_io_free.restype = None
+        L.mdd_io_last_error.restype = C.c_char_p
+        for name in ("n_lines", "raw_bytes", "n_docs"):
+            f = getattr(L, "mdd_io_" + name)
+            f.argtypes, f.restype = [C.c_void_p], C.c_uint64
+        for name in ("status", "line_no", "line_begin", "line_end", "id_kind", "id_begin", "id_end", "raw", "text", "offsets"):
+            f = getattr(L, "mdd_io_" + name)
+            f.argtypes, f.restype = [C.c_void_p], C.c_void_p
+        _io_lib = L
+    return _io_lib or None
+
+
+def _py_line(line: str, content_field: str, id_field, normalize_en: bool, on_error: str):
+    """The reference's own steps on one line -> (row_ok, id, content bytes or None)."""
+    import json
+    try:
+        row = json.loads(line)
+    except ValueError:
+        if on_error == "raise":
+            raise
+        return False, None, None
+    if not isinstance(row, dict):
+        if on_error == "raise":
+            raise TypeError("JSON line is not an object")
+        return False, None, None
+    rid = row.get(id_field) if id_field else None
+    text = row.get(content_field)
+    if isinstance(text, str) and encodable(text):
+        return True, rid, (normalize_text(text) if normalize_en else text).encode("utf8")
+    return True, rid, None
+
+
+def read_jsonl_shard(path: str, content_field: str, id_field=None, normalize_en: bool = False,
+                     on_error: str = "skip", use_native: bool = True):
+    """One JSON-lines shard (optionally gzip) -> dict with
+      ids      list, one entry per parsed row (None when the id field is absent / null)
+      line_no  uint64 [n_rows], physical 0-based line number of each row (ZH-1:42 `enumerate(f)`)
+      cand     int64 [n_docs], row index of every document that will be hashed
+      text     uint8, packed utf-8 of those documents (normalised when normalize_en)
+      offsets  uint64 [n_docs+1]
+      n_bad    lines that do not parse (skipped when on_error == "skip", as ZH-1:52-54 does)
+    The native scanner (libmdd_io.so) handles the lines it is sure about; every other line goes
+    through `_py_line`, i.e. json.loads + normalize_text exactly as the pure-Python path does, so
+    both paths return identical results (tests/test_hostio.py).  With ftfy installed the EN
+    normalisation is always done in Python (ftfy rewrites ASCII text too)."""
+    import ctypes as C
+    import json
+
+    import numpy as np
+    L = _io() if use_native else None
+    if L is None:
+        ids, line_no, cand, enc, n_bad = [], [], [], [], 0
+        for k, line in enumerate(iter_lines(path)):
+            if not line.strip():
+                continue
+            ok, rid, data = _py_line(line, content_field, id_field, normalize_en, on_error)
+            if not ok:
+                n_bad += 1
+                continue
+            if data is not None:
+                cand.append(len(ids))
+                enc.append(data)
+            ids.append(rid)
+            line_no.append(k)
+        offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+        if enc:
+            offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+        return {"ids": ids, "line_no": np.asarray(line_no, dtype=np.uint64), "cand": np.asarray(cand, dtype=np.int64),
+                "text": np.frombuffer(b"".join(enc), dtype=np.uint8), "offsets": offs, "n_bad": n_bad}
+
+    native_norm = normalize_en and _ftfy is None
+    h = C.c_void_p()
+    rc = L.mdd_io_read_jsonl(path.encode(), content_field.encode(), id_field.encode() if id_field else None,
+                             1 if native_norm else 0, C.byref(h))
+    if rc != 0:
+        raise OSError(L.mdd_io_last_error().decode("utf8", "replace"))
+    try:
+        n = int(L.mdd_io_n_lines(h))
+
+        def arr(name, dtype, count):
+            ptr = getattr(L, "mdd_io_" + name)(h)
+            if not ptr or count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8 if dtype == np.uint8 else C.c_uint64)),
+                                         shape=(count,)).copy()
+        status = arr("status", np.uint8, n)
+        line_no = arr("line_no", np.uint64, n)
+        lb, le = arr("line_begin", np.uint64, n), arr("line_end", np.uint64, n)
+        idk, idb, ide = arr("id_kind", np.uint8, n), arr("id_begin", np.uint64, n), arr("id_end", np.uint64, n)
+        raw = arr("raw", np.uint8, int(L.mdd_io_raw_bytes(h))).tobytes()
+        nd = int(L.mdd_io_n_docs(h))
+        offs = arr("offsets", np.uint64, nd + 1)
+        text = arr("text", np.uint8, int(offs[-1]) if nd else 0)
+    finally:
+        L.mdd_io_free(h)
+
+    ids = [None] * n
+    for i in np.flatnonzero(idk == 1).tolist():
+        ids[i] = raw[idb[i]:ide[i]].decode("utf8")
+    for i in np.flatnonzero(idk == 2).tolist():
+        ids[i] = json.loads(raw[idb[i]:ide[i]])
+    # documents the native pass produced, in line order; when normalisation must happen in Python
+    # (ftfy installed) the native text is the raw field and is normalised here
+    ok_rows = np.flatnonzero(status == 0)
+    pieces = None
+    if normalize_en and not native_norm:
+        pieces = {int(r): normalize_text(text[int(offs[k]):int(offs[k + 1])].tobytes().decode("utf8")).encode("utf8")
+                  for k, r in enumerate(ok_rows.tolist())}
+    fb_rows = np.flatnonzero(status == 2)
+    keep = np.ones(n, dtype=bool)
+    fb_data, n_bad = {}, 0
+    for i in fb_rows.tolist():
+        try:
+            line = raw[lb[i]:le[i]].decode("utf8")
+            ok, rid, data = _py_line(line, content_field, id_field, normalize_en, on_error)
+        except UnicodeDecodeError:
+            if on_error == "raise":
+                raise
+            ok, rid, data = False, None, None
+        if not ok:
+            keep[i] = False
+            n_bad += 1
+            continue
+        ids[i] = rid
+        if data is not None:
+            fb_data[i] = data
+    if not fb_data and pieces is None and keep.all():
+        cand = ok_rows.astype(np.int64)
+        return {"ids": ids, "line_no": line_no, "cand": cand, "text": text, "offsets": offs, "n_bad": 0}
+    # general merge: rebuild the packed text in row order
+    doc_of_row = {int(r): k for k, r in enumerate(ok_rows.tolist())}
+    new_index = np.cumsum(keep) - 1
+    enc, cand = [], []
+    for i in range(n):
+        if not keep[i]:
+            continue
+        if i in doc_of_row:
+            k = doc_of_row[i]
+            enc.append(pieces[i] if pieces is not None else text[int(offs[k]):int(offs[k + 1])].tobytes())
+            cand.append(int(new_index[i]))
+        elif i in fb_data:
+            enc.append(fb_data[i])
+            cand.append(int(new_index[i]))
+    offs2 = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs2[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+    return {"ids": [ids[i] for i in range(n) if keep[i]], "line_no": line_no[keep], "cand": np.asarray(cand, dtype=np.int64),
+            "text": np.frombuffer(b"".join(enc), dtype=np.uint8), "offsets": offs2, "n_bad": n_bad}

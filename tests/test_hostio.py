@@ -1,0 +1,147 @@
+"""CPU suite: native JSON-lines ingest (libmdd_io.so) against the pure-Python path on tricky
+input.  The native scanner must either agree with json.loads or hand the line back."""
+import gzip
+import json
+
+import numpy as np
+import pytest
+
+from map_neo_amd import hostio
+
+TRICKY = [
+    '{"doc_id": "a/1", "text": "plain ascii text, with Punctuation!  and   spaces\\tTabs"}',
+    '{"text": "escapes: \\" \\\\ \\/ \\b \\f \\n \\r \\t \\u0041 \\u00e9 \\u4e2d \\ud83d\\ude00 end", "doc_id": 7}',
+    '{"doc_id": "dup", "text": "first", "text": "second wins like a python dict"}',
+    '{"meta": {"text": "nested must not match", "doc_id": "nested"}, "doc_id": "outer", "text": "top level value"}',
+    '{"doc_id": "arr", "arr": [1, 2.5, -3e10, true, false, null, "x", {"text": "no"}, []], "text": "after array"}',
+    '{"doc_id": "nul", "text": null}',
+    '{"doc_id": "num", "text": 12345}',
+    '{"doc_id": "missing"}',
+    '{}',
+    '{"doc_id": null, "text": "null id"}',
+    '{"doc_id": "lone", "text": "lone surrogate \\ud83d here"}',
+    '{"doc_id": "lone2", "text": "low first \\udc00\\ud800"}',
+    '{"doc_id": "pairsplit", "text": "\\ud83d\\u0041"}',
+    '{"doc_id": "uni", "text": "Ünïcödé ＦＵＬＬ　ｗｉｄｔｈ İstanbul ǅ ß ΣΑΣ  中文，标点。"}',
+    '{"doc_id": "ws", "text": " \\u001c lead \\u001f\\u000b\\u000c trail \\n"}',
+    '{"doc_id": "nbsp", "text": "a\\u00a0b\\u2003c"}',
+    '  {"doc_id" : "spaces" ,\t"text" :\t"ws between tokens" }  \r',
+    '{"doc_id": "esc\\u0041id", "text": "escaped id"}',
+    '{"te\\u0078t": "escaped key equals text", "doc_id": "esckey"}',
+    '{"doc_id": "nan", "v": NaN, "text": "python accepts NaN"}',
+    '{"doc_id": "inf", "v": -Infinity, "text": "and -Infinity"}',
+    '{"doc_id": "badnum", "v": 01, "text": "leading zero is invalid"}',
+    '{"doc_id": "trail", "text": "trailing garbage"} xyz',
+    '{"doc_id": "ctrl", "text": "raw control \x01 char"}',
+    '{"doc_id": "tab", "text": "raw\ttab is invalid in strict json"}',
+    '{"doc_id": "trunc", "text": "unterminated',
+    '["not", "an", "object"]',
+    '"just a string"',
+    '42',
+    '{"doc_id": "badesc", "text": "bad \\x escape"}',
+    '{"doc_id": "badu", "text": "bad \\u12g4 escape"}',
+    '{"doc_id": "comma", "text": "trailing comma",}',
+    '{"doc_id": "single", \'text\': "single quotes"}',
+    '{"doc_id": "deep", "d": ' + '[' * 50 + ']' * 50 + ', "text": "deep nesting"}',
+    '{"doc_id": "empty", "text": ""}',
+    '{"doc_id": "del", "text": "del \x7f char and high ascii punct ~`^"}',
+    '',
+    '   ',
+    '\x1c\x1d',
+    '{"doc_id": "last", "text": "no newline at end"}',
+]
+
+
+def _write(tmp_path, gz):
+    data = ("\n".join(TRICKY)).encode("utf8")
+    # one line with invalid utf-8 bytes in the middle of the file
+    data = data.replace(b'{"doc_id": "empty"', b'{"doc_id": "badutf8", "text": "\xff\xfe"}\n{"doc_id": "empty"')
+    p = tmp_path / ("t.jsonl.gz" if gz else "t.jsonl")
+    if gz:
+        with gzip.open(p, "wb") as f:
+            f.write(data)
+    else:
+        p.write_bytes(data)
+    return str(p)
+
+
+def _same(a, b):
+    assert a["ids"] == b["ids"]
+    assert (a["line_no"] == b["line_no"]).all()
+    assert (a["cand"] == b["cand"]).all()
+    assert (a["offsets"] == b["offsets"]).all()
+    assert a["text"].tobytes() == b["text"].tobytes()
+    assert a["n_bad"] == b["n_bad"]
+
+
+@pytest.mark.parametrize("gz", [False, True])
+@pytest.mark.parametrize("normalize_en", [False, True])
+def test_native_equals_python(tmp_path, gz, normalize_en):
+    assert hostio._io() is not None, "libmdd_io.so missing: make -C map_neo_amd/csrc"
+    path = _write(tmp_path, gz)
+    if not gz:
+        # python's text reader refuses the file with invalid utf-8 as a whole; compare on a clean copy
+        clean = [l for l in TRICKY]
+        open(path, "w", encoding="utf8", newline="\n").write("\n".join(clean))
+    else:
+        with gzip.open(path, "wt", encoding="utf8", newline="\n") as f:
+            f.write("\n".join(TRICKY))
+    nat = hostio.read_jsonl_shard(path, "text", "doc_id", normalize_en, "skip", use_native=True)
+    py = hostio.read_jsonl_shard(path, "text", "doc_id", normalize_en, "skip", use_native=False)
+    _same(nat, py)
+    assert py["n_bad"] >= 10 and len(py["cand"]) >= 15
+    # spot checks against json.loads directly
+    rows = {}
+    for l in TRICKY:
+        try:
+            r = json.loads(l)
+            if isinstance(r, dict) and isinstance(r.get("doc_id"), str):
+                rows[r["doc_id"]] = r
+        except ValueError:
+            pass
+    o = nat["offsets"]
+    for k, ridx in enumerate(nat["cand"].tolist()):
+        rid = nat["ids"][ridx]
+        if isinstance(rid, str) and rid in rows:
+            want = rows[rid]["text"]
+            want = hostio.normalize_text(want) if normalize_en else want
+            assert nat["text"][int(o[k]):int(o[k + 1])].tobytes().decode("utf8") == want, rid
+
+
+def test_native_invalid_utf8_line_is_skipped(tmp_path):
+    path = _write(tmp_path, gz=False)
+    nat = hostio.read_jsonl_shard(path, "text", "doc_id", False, "skip", use_native=True)
+    assert "badutf8" not in nat["ids"] and "empty" in nat["ids"] and "last" in nat["ids"]
+
+
+def test_native_ascii_normalisation_exhaustive():
+    """every ASCII byte, in context, through the native EN normaliser == hostio.normalize_text"""
+    import os
+    import tempfile
+    texts = ["".join(chr(c) for c in range(1, 128)), "".join(f" x{chr(c)}Y {chr(c)}" for c in range(1, 128)),
+             "A  B\t\tC\n\nD\r\nE\x0bF\x0cG\x1cH\x1dI\x1eJ\x1fK", "  ...  ", "!!!", "MiXeD--CaSe__123"]
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "n.jsonl")
+        with open(p, "w", encoding="utf8", newline="\n") as f:
+            for i, t in enumerate(texts):
+                f.write(json.dumps({"doc_id": i, "text": t}) + "\n")
+        nat = hostio.read_jsonl_shard(p, "text", "doc_id", True, "raise", use_native=True)
+    o = nat["offsets"]
+    got = [nat["text"][int(o[k]):int(o[k + 1])].tobytes().decode() for k in range(len(texts))]
+    assert got == [hostio.normalize_text(t) for t in texts]
+
+
+def test_random_roundtrip_native_vs_python(tmp_path):
+    rng = np.random.Generator(np.random.PCG64(5))
+    pools = [(0x20, 0x7F), (0x80, 0x7FF), (0x800, 0xD7FF), (0xE000, 0xFFFF), (0x10000, 0x10FFFF), (0x00, 0x20)]
+    p = tmp_path / "r.jsonl"
+    with open(p, "w", encoding="utf8", newline="\n") as f:
+        for i in range(400):
+            n = int(rng.integers(0, 80))
+            cps = [int(rng.integers(*pools[int(rng.integers(0, len(pools)))])) for _ in range(n)]
+            t = "".join(chr(c) for c in cps)
+            f.write(json.dumps({"k": [i, {"text": "inner"}], "doc_id": f"d{i}", "text": t},
+                               ensure_ascii=bool(i % 2)) + "\n")
+    for norm in (False, True):
+        _same(hostio.read_jsonl_shard(str(p), "text", "doc_id", norm, "raise", True),
+              hostio.read_jsonl_shard(str(p), "text", "doc_id", norm, "raise", False))
