@@ -153,6 +153,14 @@ int mdd_components_union(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs, const 
                          const uint32_t* edge_v, uint64_t n_edges);
 int mdd_components_finish(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs);
 
+/* Spanning forest of flattened labels (multi-GPU merge; no counterpart in the
+ * reference): one edge (d, labels[d]) per document with labels[d] != d, appended to edge_u /
+ * edge_v (at most edge_cap are written; *n_edges, device u64, counts them).  A rank runs its
+ * own bucket edges through init/union/finish and ships this forest -- at most one edge per
+ * touched document -- instead of the raw edges. */
+int mdd_forest_edges(mdd_ctx* ctx, const uint32_t* labels, uint64_t n_docs, uint32_t* edge_u, uint32_t* edge_v,
+                     uint64_t edge_cap, uint64_t* n_edges);
+
 /* Removal rule.  Replaces EN:145-149 (every non-minimum member of a component is removed)
  * and ZH-4:17-22 (members [1:] of each component): removed[d] = labels[first+d] != first+d for
  * the n documents starting at global index `first`; *n_removed (device u64) = their count. */

@@ -853,6 +853,20 @@ __global__ void __launch_bounds__(256) removed_kernel(const uint32_t* labels, ui
     if (threadIdx.x == 0 && cnt) atomicAdd(n_removed, (unsigned long long)cnt);
 }
 
+// labels (flattened union-find) -> one edge (d, labels[d]) per non-root document: the spanning
+// forest a rank ships to the others instead of its raw bucket edges
+__global__ void __launch_bounds__(256) forest_edges_kernel(const uint32_t* labels, uint64_t n, uint32_t* edge_u, uint32_t* edge_v,
+                                                           uint64_t cap, unsigned long long* n_edges) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool have = false;
+    uint32_t l = 0;
+    if (i < n) {
+        l = labels[i];
+        have = l != (uint32_t)i;
+    }
+    append_edge((uint32_t)i, l, have, edge_u, edge_v, cap, n_edges);
+}
+
 // VALU calibration: dependency-free fast-class int32 ops (v_xor / v_add / v_lshrrev)
 __global__ void __launch_bounds__(256) valu_cal_kernel(uint32_t* out, int iters, uint32_t seed) {
     uint32_t acc[8];
@@ -1159,6 +1173,19 @@ int mdd_components_finish(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs) {
     if (n_docs == 0) return MDD_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(uf_flatten_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_forest_edges(mdd_ctx* ctx, const uint32_t* labels, uint64_t n_docs, uint32_t* edge_u, uint32_t* edge_v,
+                     uint64_t edge_cap, uint64_t* n_edges) {
+    REQUIRE(ctx && n_edges, "mdd_forest_edges: NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(n_edges, 0, sizeof(uint64_t), ctx->stream));
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(labels && (edge_cap == 0 || (edge_u && edge_v)), "mdd_forest_edges: NULL buffer");
+    hipLaunchKernelGGL(forest_edges_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs, edge_u,
+                       edge_v, edge_cap, reinterpret_cast<unsigned long long*>(n_edges));
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

@@ -155,7 +155,16 @@ def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: i
         if xu.size:
             eu, ev = torch.cat([eu, be.to_device(xu)]), torch.cat([ev, be.to_device(xv)])
     mark("bucket_edges")
-    # --- merge: all-gather every rank's edges, identical union-find everywhere
+    # --- merge: reduce this rank's edges to a spanning forest (at most one edge per touched
+    # document), all-gather the forests, identical union-find everywhere
+    n_local_edges = int(eu.numel())
+    if world > 1 and n_local_edges:
+        lab_local = be.components_init(n_global)
+        be.components_union(lab_local, eu, ev)
+        be.components_finish(lab_local)
+        eu, ev = be.forest_edges(lab_local, n_local_edges)
+        del lab_local
+    mark("forest")
     eu_all = _all_gather_v(eu, group)
     ev_all = _all_gather_v(ev, group)
     mark("all_gather")
@@ -167,7 +176,8 @@ def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: i
     if timings is not None:
         timings["records_sent"] = int(sum(send_counts))
         timings["records_received"] = int(sum(recv_counts))
-        timings["edges_local"] = int(eu.numel())
+        timings["edges_local"] = n_local_edges
+        timings["forest_edges_local"] = int(eu.numel())
         timings["edges_global"] = int(eu_all.numel())
     return {"sig": sig, "edge_u": eu_all, "edge_v": ev_all, "labels": labels, "removed": removed,
             "n_removed": n_removed, "n_collisions": int(coll_idx.size)}

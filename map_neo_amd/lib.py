@@ -31,6 +31,7 @@ SIGNATURES = {
     "mdd_components_init": (_int, [_vp, _vp, _u64]),
     "mdd_components_union": (_int, [_vp, _vp, _u64, _vp, _vp, _u64]),
     "mdd_components_finish": (_int, [_vp, _vp, _u64]),
+    "mdd_forest_edges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _vp]),
     "mdd_removed_mask": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "mdd_valu_calibrate": (_int, [_vp, _int, C.POINTER(C.c_double)]),
 }

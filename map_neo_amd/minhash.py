@@ -224,6 +224,16 @@ class Engine:
     def components_finish(self, labels: torch.Tensor):
         _lib.check(self.L.mdd_components_finish(self.ctx, _ptr(labels), labels.numel()), "mdd_components_finish")
 
+    def forest_edges(self, labels: torch.Tensor, max_edges: int):
+        """(d, labels[d]) for every non-root d of flattened labels; max_edges bounds the output."""
+        cap = max(1, int(max_edges))
+        eu, ev = self.empty(cap, torch.int32), self.empty(cap, torch.int32)
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.mdd_forest_edges(self.ctx, _ptr(labels), labels.numel(), _ptr(eu), _ptr(ev), cap, _ptr(cnt)),
+                   "mdd_forest_edges")
+        n = min(cap, int(cnt.item()))
+        return eu[:n], ev[:n]
+
     def removed_mask(self, labels: torch.Tensor, first: int, n: int):
         removed = self.empty(n, torch.uint8)
         cnt = torch.zeros(1, dtype=torch.int64, device=self.device)

@@ -86,6 +86,11 @@ class OracleBackend:
         labels.copy_(torch.from_numpy(lab.view(np.int32)))
         self._edges = []
 
+    def forest_edges(self, labels, max_edges):
+        lab = labels.numpy().view(np.uint32)
+        idx = np.flatnonzero(lab != np.arange(lab.shape[0], dtype=np.uint32)).astype(np.uint32)
+        return self.to_device(idx), self.to_device(lab[idx])
+
     def removed_mask(self, labels, first, n):
         lab = labels.numpy().view(np.uint32)
         rm = lab[first:first + n] != np.arange(first, first + n, dtype=np.uint32)

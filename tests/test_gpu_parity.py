@@ -312,3 +312,22 @@ def test_host_pipeline_matches_resident(engine):
     got = pipe.signatures(host, offs.cpu().numpy(), 128)
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+def test_forest_edges(engine):
+    """forest of flattened labels reproduces the same components with at most one edge per document"""
+    rng = np.random.Generator(np.random.PCG64(9))
+    n = 50000
+    edges = rng.integers(0, n, (30000, 2)).astype(np.uint32)
+    labels = engine.components_init(n)
+    eu, ev = engine.to_device(np.ascontiguousarray(edges[:, 0])), engine.to_device(np.ascontiguousarray(edges[:, 1]))
+    engine.components_union(labels, eu, ev)
+    engine.components_finish(labels)
+    fu, fv = engine.forest_edges(labels, len(edges))
+    lab = as_u32(labels)
+    assert fu.numel() == int((lab != np.arange(n)).sum()) <= len(edges)
+    l2 = engine.components_init(n)
+    engine.components_union(l2, fu, fv)
+    engine.components_finish(l2)
+    assert (as_u32(l2) == lab).all()
+    assert (lab == R.components_min_label(n, [(int(u), int(v)) for u, v in edges if u != v])).all()
