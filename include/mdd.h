@@ -167,6 +167,25 @@ int mdd_forest_edges(mdd_ctx* ctx, const uint32_t* labels, uint64_t n_docs, uint
 int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint64_t n, uint8_t* removed,
                      uint64_t* n_removed);
 
+/* Exact grouping of byte ranges (the exact-match stages around
+ * MinHash in the EN pipeline).  Replaces the "hash the unit with SHA-256, group by hash, keep the
+ * first" pattern of Exact_Document_Deduplication/exact_document_deduplication.py:16-18
+ * (dropDuplicates on the content), Paragraph_Deduplication/paragraph.py:18-23 (sha2 +
+ * row_number over (id, pos)) and Exact_Substring_Deduplication/exact_substr_dedup.py:23-24,
+ * 44-47,83 (_get_hash + groupByKey + dup_list[1:]) -- all under
+ * Matrix/english_data_clean_pipeline/dedup/.  Unit u = bytes [ubeg[u], uend[u]) of `text`
+ * (8-byte aligned, MDD_TEXT_PAD spare bytes); units may overlap.
+ *   first_of[u] = smallest unit index whose bytes are identical to unit u's (u itself if none).
+ * Equal SHA-256 <=> equal bytes, so these are the reference's groups with "first" = lowest index.
+ * A 64-bit content hash (truncated to key_bits; pass 64) only picks the table slot; units whose
+ * hash collides with a different unit's get first_of[u] = u provisionally and are listed in
+ * coll_idx / *n_coll (device u64) for exact resolution by the caller.
+ * Workspaces: key_scratch u64[n_units]; tab_key u64[tab_size], tab_rep u32[tab_size], tab_size a
+ * power of two >= 2*n_units.  avg_unit_bytes picks thread-per-unit (< 256) or wave-per-unit. */
+int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
+                    uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* tab_key, uint32_t* tab_rep,
+                    uint64_t tab_size, uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
+
 /* Measurement helper: runs `iters` iterations of a dependency-free
  * v_xor/v_add/v_lshr mix on every CU and reports the measured int32 VALU lane-op rate in
  * *tops_host (HOST double, 1e12 lane-ops/s).  Synchronous. */

@@ -1,0 +1,55 @@
+// Shared by the translation units of libmdd_hip.so (mdd_hip.hip, mdd_exact.hip).
+#ifndef MDD_COMMON_H
+#define MDD_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mdd.h"
+
+struct mdd_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    int cus;
+    // long-document segment plan (filled by seg_plan_kernel on every mdd_signatures call)
+    uint64_t* seg_items;    // device, SEG_ITEM_CAP entries of (doc << 24 | segment)
+    uint64_t* seg_n_items;  // device: [0] queued segments, [1] work counter of sig_kernel
+    uint32_t seg_bytes;     // segment length in bytes (multiple of 256)
+};
+
+namespace mddi {
+extern thread_local char g_err[512];
+int fail(int code, const char* fmt, ...);
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t below(uint64_t m) {  // set bits of m in lanes below this one
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+}  // namespace mddi
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return mddi::fail(MDD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define REQUIRE(cond, ...)                                            \
+    do {                                                              \
+        if (!(cond)) return mddi::fail(MDD_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#endif  // MDD_COMMON_H

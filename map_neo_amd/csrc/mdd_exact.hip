@@ -1,0 +1,166 @@
+// Exact grouping of byte ranges ("units") of the packed text: for every unit the smallest
+// unit index with IDENTICAL bytes.  One primitive behind the exact-match stages that bracket
+// MinHash in the reference's EN pipeline (paths relative to
+// /root/reference/Matrix/english_data_clean_pipeline/dedup):
+//   Exact_Document_Deduplication/exact_document_deduplication.py:16-18  units = documents
+//   Paragraph_Deduplication/paragraph.py:15-30                          units = "\n"-separated paragraphs
+//   Exact_Substring_Deduplication/exact_substr_dedup.py:34-47           units = 50-character windows
+// The reference groups on SHA-256 of the unit; equal SHA-256 <=> equal bytes (no collision is
+// known), so grouping on the bytes themselves gives the same groups.  A 64-bit content hash only
+// selects the hash-table slot; membership is decided by comparing the bytes, and units whose
+// hash collides with a different unit's are reported for exact resolution by the caller.
+// HBM-bound: every unit's bytes are read twice (hash, verify) plus ~2 random 8-byte atomics.
+#include "mdd_common.h"
+
+namespace {
+using namespace mddi;
+
+constexpr uint64_t C1 = 0x9E3779B97F4A7C15ULL, C2 = 0xD6E8FEB86659FD93ULL;
+
+// 8 bytes at absolute byte address a (any alignment) from an 8-byte aligned base; the allocation
+// extends MDD_TEXT_PAD bytes past the text, so the second load is always in bounds
+__device__ __forceinline__ uint64_t load8(const uint64_t* t64, uint64_t a) {
+    uint64_t i = a >> 3;
+    uint32_t sh = (uint32_t)(a & 7) * 8;
+    uint64_t lo = t64[i];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (t64[i + 1] << (64 - sh));
+}
+
+// order-sensitive, position-mixed SUM over 8-byte chunks: chunks can be hashed in any order and
+// by any number of lanes (thread-per-unit and wave-per-unit kernels give the same value)
+__device__ __forceinline__ uint64_t chunk_term(const uint64_t* t64, uint64_t b, uint64_t len, uint64_t c) {
+    uint64_t v = load8(t64, b + 8 * c);
+    uint64_t rem = len - 8 * c;
+    if (rem < 8) v &= (1ULL << (8 * rem)) - 1;  // rem >= 1 here
+    return mix64(v + C1 * (c + 1));
+}
+__device__ __forceinline__ uint64_t finish_key(uint64_t sum, uint64_t len, int key_bits) {
+    uint64_t h = mix64(sum ^ (len * C2) ^ C1);
+    if (key_bits < 64) h &= (1ULL << key_bits) - 1;
+    return h ? h : 1ULL;
+}
+
+__global__ void __launch_bounds__(256) exact_hash_thread_kernel(const uint64_t* t64, const uint64_t* ubeg, const uint64_t* uend,
+                                                                uint64_t n, int key_bits, uint64_t* key) {
+    uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    uint64_t b = ubeg[u], len = uend[u] - b, nch = (len + 7) >> 3, sum = 0;
+    for (uint64_t c = 0; c < nch; c++) sum += chunk_term(t64, b, len, c);
+    key[u] = finish_key(sum, len, key_bits);
+}
+
+// one wave per unit: for long units (documents)
+__global__ void __launch_bounds__(256) exact_hash_wave_kernel(const uint64_t* t64, const uint64_t* ubeg, const uint64_t* uend,
+                                                              uint64_t n, int key_bits, uint64_t* key) {
+    uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= n) return;
+    uint32_t lane = lane_id();
+    uint64_t b = ubeg[u], len = uend[u] - b, nch = (len + 7) >> 3, sum = 0;
+    for (uint64_t c = lane; c < nch; c += 64) sum += chunk_term(t64, b, len, c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)sum, o, 64);
+        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(sum >> 32), o, 64);
+        sum += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) key[u] = finish_key(sum, len, key_bits);
+}
+
+__global__ void __launch_bounds__(256) exact_insert_kernel(const uint64_t* key, uint64_t n, unsigned long long* tab_key,
+                                                           uint32_t* tab_rep, uint64_t tab_mask) {
+    uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    unsigned long long k = key[u];
+    uint64_t slot = mix64(k) & tab_mask;
+    for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: the table is at most half full
+        unsigned long long cur = atomicCAS(&tab_key[slot], 0ULL, k);
+        if (cur == 0ULL || cur == k) {
+            atomicMin(&tab_rep[slot], (uint32_t)u);
+            return;
+        }
+        slot = (slot + 1) & tab_mask;
+    }
+}
+
+__global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, const uint64_t* ubeg, const uint64_t* uend,
+                                                         const uint64_t* key, uint64_t n, const unsigned long long* tab_key,
+                                                         const uint32_t* tab_rep, uint64_t tab_mask, uint32_t* first_of,
+                                                         uint64_t* coll_idx, uint64_t coll_cap, unsigned long long* n_coll) {
+    uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    unsigned long long k = key[u];
+    uint64_t slot = mix64(k) & tab_mask;
+    uint32_t rep = (uint32_t)u;
+    for (uint64_t probe = 0; probe <= tab_mask; probe++) {
+        unsigned long long cur = tab_key[slot];
+        if (cur == k) {
+            rep = tab_rep[slot];
+            break;
+        }
+        if (cur == 0ULL) break;
+        slot = (slot + 1) & tab_mask;
+    }
+    uint32_t out = (uint32_t)u;
+    if (rep != (uint32_t)u) {
+        uint64_t b = ubeg[u], len = uend[u] - b, rb = ubeg[rep], rlen = uend[rep] - rb;
+        bool same = len == rlen;
+        uint64_t nch = (len + 7) >> 3;
+        for (uint64_t c = 0; same && c < nch; c++) {
+            uint64_t x = load8(t64, b + 8 * c), y = load8(t64, rb + 8 * c);
+            uint64_t rem = len - 8 * c;
+            if (rem < 8) {
+                uint64_t m = (1ULL << (8 * rem)) - 1;
+                x &= m;
+                y &= m;
+            }
+            same = x == y;
+        }
+        if (same) out = rep;
+        else {
+            unsigned long long o = atomicAdd(n_coll, 1ULL);
+            if (o < coll_cap) coll_idx[o] = u;
+        }
+    }
+    first_of[u] = out;
+}
+
+}  // namespace
+
+extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
+                               uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* tab_key,
+                               uint32_t* tab_rep, uint64_t tab_size, uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap,
+                               uint64_t* n_coll) {
+    REQUIRE(ctx && n_coll, "mdd_exact_group: NULL argument");
+    REQUIRE(key_bits >= 1 && key_bits <= 64, "mdd_exact_group: key_bits=%d outside [1,64]", key_bits);
+    REQUIRE(n_units <= 0xFFFFFFFEull, "mdd_exact_group: n_units=%llu exceeds 2^32-2", (unsigned long long)n_units);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(n_coll, 0, sizeof(uint64_t), ctx->stream));
+    if (n_units == 0) return MDD_OK;
+    REQUIRE(text && ubeg && uend && key_scratch && tab_key && tab_rep && first_of && (coll_cap == 0 || coll_idx),
+            "mdd_exact_group: NULL buffer");
+    REQUIRE((reinterpret_cast<uintptr_t>(text) & 7u) == 0, "mdd_exact_group: text must be 8-byte aligned");
+    REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_units,
+            "mdd_exact_group: tab_size=%llu must be a power of two >= 2*n_units", (unsigned long long)tab_size);
+    const uint64_t* t64 = reinterpret_cast<const uint64_t*>(text);
+    if (avg_unit_bytes >= 256) {
+        REQUIRE(n_units * 64 / 256 + 1 < 0x7FFFFFFFull, "mdd_exact_group: too many units for one launch");
+        hipLaunchKernelGGL(exact_hash_wave_kernel, dim3(grid_for(n_units * 64, 256)), dim3(256), 0, ctx->stream, t64, ubeg, uend,
+                           n_units, key_bits, key_scratch);
+    } else {
+        hipLaunchKernelGGL(exact_hash_thread_kernel, dim3(grid_for(n_units, 256)), dim3(256), 0, ctx->stream, t64, ubeg, uend,
+                           n_units, key_bits, key_scratch);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(tab_key, 0, sizeof(uint64_t) * tab_size, ctx->stream));
+    HIP_TRY(hipMemsetAsync(tab_rep, 0xFF, sizeof(uint32_t) * tab_size, ctx->stream));
+    unsigned g = grid_for(n_units, 256);
+    hipLaunchKernelGGL(exact_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key_scratch, n_units,
+                       reinterpret_cast<unsigned long long*>(tab_key), tab_rep, tab_size - 1);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(exact_link_kernel, dim3(g), dim3(256), 0, ctx->stream, t64, ubeg, uend, key_scratch, n_units,
+                       reinterpret_cast<const unsigned long long*>(tab_key), tab_rep, tab_size - 1, first_of, coll_idx, coll_cap,
+                       reinterpret_cast<unsigned long long*>(n_coll));
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}

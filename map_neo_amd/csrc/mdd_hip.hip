@@ -17,26 +17,11 @@
 #include <cstdio>
 #include <cstring>
 
-#include "../../include/mdd.h"
 
-// ------------------------------------------------------------------------------------------
-// host-side plumbing
-// ------------------------------------------------------------------------------------------
-struct mdd_ctx {
-    int device;
-    hipStream_t stream;
-    bool owns_stream;
-    int cus;
-    // long-document segment plan (filled by seg_plan_kernel on every mdd_signatures call)
-    uint64_t* seg_items;    // device, SEG_ITEM_CAP entries of (doc << 24 | segment)
-    uint64_t* seg_n_items;  // device counter
-    uint32_t seg_bytes;     // segment length in bytes (multiple of 256)
-};
+#include "mdd_common.h"
 
-namespace {
-
+namespace mddi {
 thread_local char g_err[512] = "";
-
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -44,19 +29,10 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+}  // namespace mddi
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(MDD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
-                        __FILE__, __LINE__);                                                  \
-    } while (0)
-
-#define REQUIRE(cond, ...)                                   \
-    do {                                                     \
-        if (!(cond)) return fail(MDD_ERR_INVALID, __VA_ARGS__); \
-    } while (0)
+namespace {
+using namespace mddi;
 
 constexpr uint64_t P61 = (1ULL << 61) - 1;
 
@@ -237,10 +213,6 @@ __device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint32_t p, uin
 // ------------------------------------------------------------------------------------------
 // device: wave helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ uint32_t below(uint64_t m) {  // set bits of m in lanes below this one
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ uint32_t wave_max(uint32_t x) {
 #pragma unroll
@@ -635,15 +607,6 @@ __global__ void __launch_bounds__(256) seg_plan_kernel(const uint64_t* offsets, 
 // ------------------------------------------------------------------------------------------
 // band keys, routing, bucketing, union-find (HBM-bound; one thread per record / document)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
-    x ^= x >> 30;
-    x *= 0xbf58476d1ce4e5b9ULL;
-    x ^= x >> 27;
-    x *= 0x94d049bb133111ebULL;
-    x ^= x >> 31;
-    return x;
-}
-
 __device__ __forceinline__ uint64_t tuple_key(const uint32_t* t, int rows, uint32_t band, int key_bits) {
     uint64_t h = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)band * 0xD6E8FEB86659FD93ULL);
     for (int i = 0; i < rows; i++) h = mix64(h ^ t[i]) + 0x9E3779B97F4A7C15ULL;
@@ -887,7 +850,6 @@ __global__ void __launch_bounds__(256) valu_cal_kernel(uint32_t* out, int iters,
     if (r == 0x12345678u) out[0] = r;
 }
 
-inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 int check_sig_common(const char* fn, mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, int unit, int width) {
     REQUIRE(ctx != nullptr, "%s: ctx is NULL", fn);
@@ -923,7 +885,7 @@ extern "C" {
 
 int mdd_version(void) { return 100; }
 
-const char* mdd_last_error(void) { return g_err; }
+const char* mdd_last_error(void) { return mddi::g_err; }
 
 int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     REQUIRE(out != nullptr, "mdd_ctx_create: out is NULL");

@@ -1,0 +1,86 @@
+"""GPU suite: exact-match stages against their oracle restatement."""
+import numpy as np
+import pytest
+
+from map_neo_amd import exact
+from map_neo_amd.minhash import as_u32, pack_texts
+from oracle import ref_exact as RX
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(rng, n):
+    words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "数据", "清洗", "去重", "😀", "naïve"]
+    paras = [" ".join(rng.choice(words, int(rng.integers(1, 25)))) for _ in range(60)] + ["", "", "short"]
+    docs = []
+    for _ in range(n):
+        k = int(rng.integers(0, 9))
+        docs.append("\n".join(rng.choice(paras, k)) if k else "")
+    for _ in range(n // 5):
+        docs.append(docs[int(rng.integers(0, n))])                           # exact copies
+    return docs
+
+
+def test_exact_group_primitive(engine):
+    rng = np.random.Generator(np.random.PCG64(3))
+    units = [bytes(rng.integers(97, 100, int(rng.integers(0, 40))).astype(np.uint8)) for _ in range(5000)]
+    units += [b"x" * 300, b"x" * 300, b"x" * 299, b"", b""]
+    buf, offs = pack_texts(units)
+    first = {}
+    exp = np.array([first.setdefault(u, i) for i, u in enumerate(units)], dtype=np.uint32)
+    for key_bits in (64, 6):                                                  # 6 bits: massive slot collisions, host resolution
+        got = as_u32(engine.exact_group(engine.to_device(buf), engine.to_device(offs[:-1].copy()),
+                                        engine.to_device(offs[1:].copy()), key_bits, text_host=buf))
+        assert (got == exp).all(), key_bits
+    assert engine.last_exact_collisions > 0
+    # wave-per-unit hashing (long units) gives the same groups
+    long_units = [bytes(rng.integers(97, 99, 700).astype(np.uint8)) for _ in range(50)]
+    long_units += long_units[:10] + [long_units[0][:-1] + b"!"]
+    buf, offs = pack_texts(long_units)
+    first = {}
+    exp = np.array([first.setdefault(u, i) for i, u in enumerate(long_units)], dtype=np.uint32)
+    got = as_u32(engine.exact_group(engine.to_device(buf), engine.to_device(offs[:-1].copy()), engine.to_device(offs[1:].copy())))
+    assert (got == exp).all()
+
+
+def test_exact_document_dedup(engine):
+    rng = np.random.Generator(np.random.PCG64(4))
+    docs = _corpus(rng, 400)
+    docs[7] = None
+    docs[90] = None
+    keep = exact.exact_document_dedup(engine, docs)
+    assert keep.tolist() == RX.exact_document_dedup(docs)
+    assert 0 < keep.sum() < len(docs)
+
+
+@pytest.mark.parametrize("key_bits", [64, 5])
+def test_paragraph_dedup(engine, key_bits):
+    rng = np.random.Generator(np.random.PCG64(5))
+    docs = _corpus(rng, 300)
+    ids = [f"doc-{int(i):05d}" for i in rng.permutation(len(docs))]
+    rows = list(zip(ids, docs))
+    rows[11] = (rows[11][0], None)
+    got = exact.paragraph_dedup(engine, rows, min_len=20, key_bits=key_bits)
+    exp = RX.paragraph_dedup(rows, min_len=20)
+    assert got == exp
+    assert 0 < len(got) < len(rows)
+
+
+@pytest.mark.parametrize("key_bits", [64, 7])
+def test_exact_substr_dedup(engine, key_bits):
+    rng = np.random.Generator(np.random.PCG64(6))
+    base = ["".join(chr(int(c)) for c in rng.integers(0x61, 0x7B, 400)) for _ in range(12)]
+    zh = ["".join(chr(int(c)) for c in rng.integers(0x4E00, 0x4F00, 200)) for _ in range(6)]
+    rows = []
+    for i in range(60):
+        parts = []
+        for _ in range(int(rng.integers(1, 4))):
+            src = base[int(rng.integers(0, 12))] if rng.random() < 0.7 else zh[int(rng.integers(0, 6))]
+            a = int(rng.integers(0, len(src) - 60))
+            parts.append(src[a:a + int(rng.integers(30, 150))])
+        rows.append((" 😀 ".join(parts), f"id{i}"))
+    rows += [("short text", "s1"), ("", "s2"), ("x" * 50, "s3"), ("y" * 51, "s4"), ("y" * 120, "s5")]
+    got = exact.exact_substr_dedup(engine, rows, 50, 20, key_bits=key_bits)
+    exp = RX.exact_substr_dedup(rows, 50, 20)
+    assert got == exp
+    assert sum(len(t) for _, t in got) < sum(len(t) for t, _ in rows)
