@@ -186,6 +186,20 @@ int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, con
                     uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* tab_key, uint32_t* tab_rep,
                     uint64_t tab_size, uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
 
+/* EN normalisation of pure-ASCII documents on the device.  Replaces
+ * normalize_text EN:31-40 (fix_text/NFC: identity on clean ASCII; lower; delete
+ * string.punctuation; strip; whitespace runs -> one space) for the documents where that needs no
+ * Unicode tables.  Two calls with the caller's exclusive scan of out_len in between:
+ *   count: out_len[d] = normalised length, non_ascii[d] = 1 when document d holds a byte >= 0x80
+ *          (then out_len[d] = 0 and the caller normalises that document with the Python steps);
+ *   write: normalised bytes of every document with non_ascii[d] == 0 to
+ *          out_text[out_offsets[d] .. out_offsets[d] + out_len[d]).
+ * All pointers are device memory. */
+int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs, uint64_t* out_len,
+                           uint8_t* non_ascii);
+int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs,
+                           const uint8_t* non_ascii, const uint64_t* out_offsets, uint8_t* out_text);
+
 /* Measurement helper: runs `iters` iterations of a dependency-free
  * v_xor/v_add/v_lshr mix on every CU and reports the measured int32 VALU lane-op rate in
  * *tops_host (HOST double, 1e12 lane-ops/s).  Synchronous. */

@@ -51,30 +51,25 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def _parse_shard(task):
+    """pool worker: one shard -> ids of all rows, candidate rows, packed text ready to hash and (Parquet,
+    --normalize en) the pure-ASCII documents that the device still has to normalise (hostio)."""
     path, id_field, content_field, normalize = task
     from .. import hostio
     name = os.path.basename(path)
-    if not path.lower().endswith((".parquet", ".pq")):
-        r = hostio.read_jsonl_shard(path, content_field, id_field, normalize_en=(normalize == "en"), on_error="skip")
-        ids, synthetic = r["ids"], False
-        for k, rid in enumerate(ids):
-            if rid is None:
-                ids[k], synthetic = f"{name}@{int(r['line_no'][k])}", True
-        return ids, r["cand"], r["text"], r["offsets"], synthetic
-    ids, cand, enc, synthetic = [], [], [], False
-    for k, row in enumerate(hostio.iter_records(path, [id_field, content_field])):
-        rid = row.get(id_field) if isinstance(row, dict) else None
+    if path.lower().endswith((".parquet", ".pq")):
+        r = hostio.read_parquet_shard(path, content_field, id_field, normalize_en=(normalize == "en"))
+        row_of = list(range(len(r["ids"])))
+    else:
+        j = hostio.read_jsonl_shard(path, content_field, id_field, normalize_en=(normalize == "en"), on_error="skip")
+        r = {"ids": j["ids"], "cand": j["cand"], "text": j["text"], "offsets": j["offsets"],
+             "ready": np.arange(len(j["cand"]), dtype=np.int64), "raw_text": np.zeros(0, np.uint8),
+             "raw_offsets": np.zeros(1, np.uint64), "raw": np.zeros(0, np.int64)}
+        row_of = j["line_no"].tolist()
+    r["synthetic"] = False
+    for k, rid in enumerate(r["ids"]):
         if rid is None:
-            rid, synthetic = f"{name}@{k}", True
-        text = row.get(content_field) if isinstance(row, dict) else None
-        if isinstance(text, str) and hostio.encodable(text):
-            cand.append(len(ids))
-            enc.append((hostio.normalize_text(text) if normalize == "en" else text).encode("utf8"))
-        ids.append(rid)
-    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
-    if enc:
-        offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
-    return ids, np.asarray(cand, dtype=np.int64), np.frombuffer(b"".join(enc), dtype=np.uint8), offs, synthetic
+            r["ids"][k], r["synthetic"] = f"{name}@{int(row_of[k])}", True
+    return r
 
 
 def _loads_or_none(line):
@@ -119,15 +114,29 @@ def run(args) -> dict:
         from ..minhash import Engine, as_u32, padded_size
         eng = Engine(args.device)
         sigs, all_ids, cand_ids, any_synth = [], [], [], False
-        for ids, cand, text, offs, synthetic in parsed:
-            any_synth |= synthetic
+        def padded(text):
+            buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+            buf[: text.size] = text
+            return eng.to_device(buf)
+
+        for r in parsed:
+            ids, cand = r["ids"], r["cand"]
+            any_synth |= r["synthetic"]
             all_ids.extend(ids)
-            if len(cand):
-                buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-                buf[: text.size] = text
-                sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
-                                           args.ngram_unit, args.seed, text_bytes=int(text.size)))
-                cand_ids.extend(ids[i] for i in cand.tolist())
+            if len(cand) == 0:
+                continue
+            sig = torch.empty((len(cand), args.num_perm), dtype=torch.int32, device=eng.device)
+            if len(r["ready"]):
+                s_ready = eng.signatures(padded(r["text"]), eng.to_device(r["offsets"]), args.num_perm, args.width,
+                                         args.ngram_unit, args.seed, text_bytes=int(r["text"].size))
+                sig[eng.to_device(r["ready"])] = s_ready
+            if len(r["raw"]):                        # EN:31-40 for pure-ASCII documents, on the device
+                n_text, n_offs, flags = eng.normalize_en(padded(r["raw_text"]), eng.to_device(r["raw_offsets"]))
+                assert int(flags.sum().item()) == 0
+                s_raw = eng.signatures(n_text, n_offs, args.num_perm, args.width, args.ngram_unit, args.seed)
+                sig[eng.to_device(r["raw"])] = s_raw
+            sigs.append(sig)
+            cand_ids.extend(ids[i] for i in cand.tolist())
         t1 = time.time()
         n = len(cand_ids)
         sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)

@@ -1,0 +1,99 @@
+// EN text normalisation on the device for pure-ASCII documents.
+// Restates normalize_text, Matrix/english_data_clean_pipeline/dedup/Minhash_Lsh_Deduplication/
+// minhashLsh.py:31-40, on the inputs where it needs no Unicode tables:
+//   ftfy.fix_text(normalization="NFC")  identity on clean ASCII (NFC never changes ASCII; with ftfy
+//                                       installed the host keeps doing this step, see hostio.py)
+//   .lower()                            A-Z -> a-z
+//   translate(PUNCTUATION -> None)      the 32 characters of string.punctuation are deleted
+//   .strip()                            leading / trailing whitespace removed
+//   re.sub(r"\s+", " ")                 every remaining whitespace run becomes one space
+// ASCII whitespace as Python's str.isspace / re \s see it: 0x09-0x0D, 0x1C-0x1F, 0x20.
+// Documents holding any byte >= 0x80 are flagged and produce no output: the caller runs the
+// Python steps on exactly those.  One wave per document, 64 bytes per step; the output position of
+// every byte comes from ballots + popcounts, so there is no scan and no LDS.  HBM-bound: the text
+// is read twice (count, write) and the normalised text written once.
+#include "mdd_common.h"
+
+namespace {
+using namespace mddi;
+
+__device__ __forceinline__ bool is_punct(uint32_t c) {
+    return (c - 33u <= 14u) | (c - 58u <= 6u) | (c - 91u <= 5u) | (c - 123u <= 3u);
+}
+__device__ __forceinline__ bool is_space(uint32_t c) { return (c - 9u <= 4u) | (c - 28u <= 4u); }
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ offs, uint64_t n,
+                                                      uint64_t* out_len, uint8_t* non_ascii,
+                                                      const uint64_t* __restrict__ out_offs, uint8_t* __restrict__ out_text) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;  // lanes below this one
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        if (WRITE && non_ascii[d]) continue;
+        const uint64_t b = offs[d], e = offs[d + 1];
+        const uint64_t o = WRITE ? out_offs[d] : 0;
+        uint64_t cnt = 0;
+        bool prev_ws = false, seen = false, bad = false;  // wave-uniform carries between 64-byte steps
+        for (uint64_t p = b; p < e; p += 64) {
+            const uint64_t i = p + lane;
+            const bool in = i < e;
+            uint32_t c = in ? text[i] : 0u;
+            if (!WRITE && __ballot(c >= 128u)) {
+                bad = true;
+                break;
+            }
+            const bool keep = in && !is_punct(c);
+            const bool ws = is_space(c);
+            const uint64_t K = __ballot(keep), W = __ballot(keep && ws), N = K & ~W;
+            const bool is_n = (N >> lane) & 1;
+            const uint64_t pk = K & lt;
+            const bool pws = pk ? ((W >> (63 - __builtin_clzll(pk))) & 1) : prev_ws;  // previous kept byte is whitespace
+            const bool sp = is_n && pws && (seen || (N & lt));                          // a space precedes this byte
+            const uint64_t S = __ballot(sp);
+            if (WRITE && is_n) {
+                uint64_t pos = o + cnt + __builtin_popcountll(N & lt) + __builtin_popcountll(S & lt);
+                if (sp) out_text[pos++] = ' ';
+                out_text[pos] = (uint8_t)((c - 65u <= 25u) ? c + 32u : c);
+            }
+            cnt += __builtin_popcountll(N) + __builtin_popcountll(S);
+            if (K) prev_ws = (W >> (63 - __builtin_clzll(K))) & 1;
+            seen = seen || N;
+        }
+        if (!WRITE && lane == 0) {
+            out_len[d] = bad ? 0 : cnt;
+            non_ascii[d] = bad;
+        }
+    }
+}
+
+unsigned norm_grid(const mdd_ctx* ctx, uint64_t n) {
+    uint64_t blocks = (n + 3) / 4, cap = (uint64_t)ctx->cus * 64;
+    return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+}  // namespace
+
+extern "C" int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs, uint64_t* out_len,
+                                      uint8_t* non_ascii) {
+    REQUIRE(ctx, "mdd_normalize_en_count: NULL context");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(text && offsets && out_len && non_ascii, "mdd_normalize_en_count: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(norm_en_kernel<false>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, offsets, n_docs, out_len,
+                       non_ascii, (const uint64_t*)nullptr, (uint8_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+extern "C" int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs,
+                                      const uint8_t* non_ascii, const uint64_t* out_offsets, uint8_t* out_text) {
+    REQUIRE(ctx, "mdd_normalize_en_write: NULL context");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(text && offsets && non_ascii && out_offsets && out_text, "mdd_normalize_en_write: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(norm_en_kernel<true>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, offsets, n_docs,
+                       (uint64_t*)nullptr, const_cast<uint8_t*>(non_ascii), out_offsets, out_text);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}

@@ -253,3 +253,96 @@ def read_jsonl_shard(path: str, content_field: str, id_field=None, normalize_en:
         offs2[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
     return {"ids": [ids[i] for i in range(n) if keep[i]], "line_no": line_no[keep], "cand": np.asarray(cand, dtype=np.int64),
             "text": np.frombuffer(b"".join(enc), dtype=np.uint8), "offsets": offs2, "n_bad": n_bad}
+
+
+# ------------------------------------------------------------------------------------------
+# Parquet ingest without per-row Python objects: Arrow string buffers are already the packed
+# utf-8 + offsets layout mdd_signatures consumes
+# ------------------------------------------------------------------------------------------
+def read_parquet_shard(path: str, content_field: str, id_field=None, normalize_en: bool = False):
+    """One Parquet shard -> dict with
+      ids        list, one entry per row (None when the id column is absent / null)
+      cand       int64 [n_docs], row index of every document that will be hashed (content is a
+                 non-null, valid utf-8 string; EN:124, ZH-1:52-54)
+      text, offsets        packed utf-8 of the documents that are READY to hash
+      ready      int64, position in `cand` of each of those documents
+      raw_text, raw_offsets, raw   pure-ASCII documents still to be normalised (EN:31-40) --
+                 on the device with Engine.normalize_en -- and their positions in `cand`
+    Without normalize_en every document is ready.  With it, documents holding non-ASCII bytes
+    (or all documents when ftfy is installed, which rewrites ASCII text too) are normalised here
+    by `normalize_text`; the rest is left to the device."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    pf = pq.ParquetFile(path)
+    names = pf.schema_arrow.names
+    tbl = pf.read(columns=[c for c in dict.fromkeys((id_field, content_field)) if c and c in names])
+    n = tbl.num_rows
+    ids = tbl.column(id_field).to_pylist() if id_field and id_field in names else [None] * n
+    e8, e64 = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+    out = {"ids": ids, "cand": np.zeros(0, np.int64), "text": e8, "offsets": e64, "ready": np.zeros(0, np.int64),
+           "raw_text": e8, "raw_offsets": e64, "raw": np.zeros(0, np.int64)}
+    if content_field not in names:
+        return out
+    col = tbl.column(content_field)
+    if not (pa.types.is_string(col.type) or pa.types.is_large_string(col.type)):
+        return out
+    arr = col.cast(pa.large_string()).combine_chunks()
+    if isinstance(arr, pa.ChunkedArray):
+        arr = arr.chunk(0) if arr.num_chunks else pa.array([], pa.large_string())
+    valid = np.asarray(arr.is_valid())
+    arr = arr.drop_null()
+    try:
+        arr.validate(full=True)                      # utf-8 validity of every value
+        bad = None
+    except pa.ArrowInvalid:
+        bad = []
+    bufs = arr.buffers()
+    offs = np.frombuffer(bufs[1], dtype=np.int64)[arr.offset: arr.offset + len(arr) + 1].astype(np.uint64)
+    data = np.frombuffer(bufs[2], dtype=np.uint8) if bufs[2] is not None else e8
+    cand = np.flatnonzero(valid).astype(np.int64)
+    if bad is not None:                              # rare: find the rows that are not utf-8 and leave them unhashed
+        for k in range(len(arr)):
+            try:
+                data[int(offs[k]):int(offs[k + 1])].tobytes().decode("utf8")
+            except UnicodeDecodeError:
+                bad.append(k)
+        keep = np.ones(len(arr), dtype=bool)
+        keep[bad] = False
+        cand = cand[keep]
+        pieces = [data[int(offs[k]):int(offs[k + 1])].tobytes() for k in np.flatnonzero(keep).tolist()]
+        data = np.frombuffer(b"".join(pieces), dtype=np.uint8)
+        offs = np.zeros(len(pieces) + 1, dtype=np.uint64)
+        if pieces:
+            offs[1:] = np.cumsum([len(p) for p in pieces], dtype=np.uint64)
+    base = int(offs[0]) if len(offs) else 0
+    data = data[base:int(offs[-1])] if len(offs) else e8
+    offs = offs - np.uint64(base)
+    out["cand"] = cand
+    nd = len(cand)
+    if not normalize_en:
+        out.update(text=data, offsets=offs, ready=np.arange(nd, dtype=np.int64))
+        return out
+    if _ftfy is not None:
+        host = np.arange(nd, dtype=np.int64)
+    else:
+        hi = np.flatnonzero(data >= 0x80).astype(np.uint64)
+        host = np.unique(np.searchsorted(offs, hi, side="right") - 1).astype(np.int64)
+    pieces = [normalize_text(data[int(offs[k]):int(offs[k + 1])].tobytes().decode("utf8")).encode("utf8") for k in host.tolist()]
+    t_off = np.zeros(len(pieces) + 1, dtype=np.uint64)
+    if pieces:
+        t_off[1:] = np.cumsum([len(p) for p in pieces], dtype=np.uint64)
+    out.update(text=np.frombuffer(b"".join(pieces), dtype=np.uint8), offsets=t_off, ready=host)
+    is_raw = np.ones(nd, dtype=bool)
+    is_raw[host] = False
+    raw = np.flatnonzero(is_raw).astype(np.int64)
+    if len(host) == 0:
+        out.update(raw_text=data, raw_offsets=offs, raw=raw)
+    elif len(raw):
+        lens = (offs[1:] - offs[:-1])[raw].astype(np.int64)
+        r_off = np.zeros(len(raw) + 1, dtype=np.uint64)
+        r_off[1:] = np.cumsum(lens).astype(np.uint64)
+        # gather the byte ranges of the raw documents
+        src = np.repeat(offs[:-1][raw].astype(np.int64) - r_off[:-1].astype(np.int64), lens) + np.arange(int(r_off[-1]), dtype=np.int64)
+        out.update(raw_text=data[src], raw_offsets=r_off, raw=raw)
+    return out

@@ -276,6 +276,23 @@ class Engine:
         self.last_exact_collisions = n_coll
         return first_of
 
+    def normalize_en(self, text: torch.Tensor, offsets: torch.Tensor):
+        """EN:31-40 on the pure-ASCII documents of a packed batch, on the device.  Returns
+        (out_text uint8 [padded], out_offsets int64 [n+1], non_ascii uint8 [n]); documents with
+        non_ascii[d] == 1 have zero length in the output and must be normalised by the caller."""
+        n = offsets.numel() - 1
+        out_len = torch.zeros(max(n, 0), dtype=torch.int64, device=self.device)
+        flags = torch.zeros(max(n, 0), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.mdd_normalize_en_count(self.ctx, _ptr(text), _ptr(offsets), n, _ptr(out_len), _ptr(flags)),
+                   "mdd_normalize_en_count")
+        out_offs = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(out_len, 0, out=out_offs[1:])
+        total = int(out_offs[-1].item()) if n > 0 else 0
+        out_text = torch.zeros(padded_size(total), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.mdd_normalize_en_write(self.ctx, _ptr(text), _ptr(offsets), n, _ptr(flags), _ptr(out_offs),
+                                                 _ptr(out_text)), "mdd_normalize_en_write")
+        return out_text, out_offs, flags
+
     def valu_calibrate(self, iters: int = 20000) -> float:
         out = C.c_double(0.0)
         _lib.check(self.L.mdd_valu_calibrate(self.ctx, iters, C.byref(out)), "mdd_valu_calibrate")

@@ -179,3 +179,40 @@ def test_stage_entry_point_jsonl_and_parquet(tmp_path, mini_docs):
     rows = [json.loads(l) for p in sorted(os.listdir(out / "shards")) for l in gzip.open(out / "shards" / p, "rt", encoding="utf8")]
     assert {r["doc_id"] for r in rows} == set(ids) - exp_removed
     assert any("extra" in r for r in rows)
+
+
+def test_stage_entry_point_parquet_device_normalisation(tmp_path, mini_docs):
+    """Parquet + --normalize en: ASCII documents are normalised on the device, the others by the
+    Python steps in the pool; result == oracle dedup of the Python-normalised texts"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from map_neo_amd import hostio
+    from map_neo_amd.cli import dedup as stage
+    rng = np.random.Generator(np.random.PCG64(21))
+    docs = []
+    for i, t in enumerate(mini_docs):
+        if t.isascii() and i % 2:
+            t = "  " + t.upper().replace(" ", " ,\t ", 3) + "!! "          # same document after EN:31-40
+        docs.append(t)
+    docs[5] = None
+    n = len(docs)
+    ids = [f"id{(i * 41) % n:04d}" for i in range(n)]
+    inp = tmp_path / "in"
+    inp.mkdir()
+    pq.write_table(pa.table({"doc_id": ids[:100], "raw_content": docs[:100]}), inp / "a.parquet", row_group_size=17)
+    pq.write_table(pa.table({"doc_id": ids[100:], "raw_content": docs[100:]}), inp / "b.parquet")
+    out = tmp_path / "out"
+    s = stage.run(stage.build_parser().parse_args(["--input_dir", str(inp), "--output_dir", str(out), "--normalize", "en",
+                                                   "--workers", "2"]))
+    hashed = [k for k in range(n) if docs[k] is not None]
+    lab = R.dedup([hostio.normalize_text(docs[k]) for k in hashed])["labels"]
+    comp = {}
+    for j, k in enumerate(hashed):
+        comp.setdefault(int(lab[j]), []).append(k)
+    exp_removed = set()
+    for members in comp.values():
+        keep = min(ids[k] for k in members)
+        exp_removed |= {ids[k] for k in members if ids[k] != keep}
+    assert set(open(out / "removed_ids.txt").read().split()) == exp_removed
+    assert ids[5] in set(open(out / "kept_ids.txt").read().split())
+    assert s["n_hashed"] == n - 1 and len(exp_removed) > 0

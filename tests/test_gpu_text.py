@@ -1,0 +1,55 @@
+"""GPU suite: EN normalisation of pure-ASCII documents on the device
+against the Python statement of EN:31-40 (hostio.normalize_text; without ftfy)."""
+import numpy as np
+import pytest
+
+from map_neo_amd import hostio
+from map_neo_amd.minhash import as_u64, pack_texts
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(engine, docs):
+    buf, offs = pack_texts(docs)
+    t, o, f = engine.normalize_en(engine.to_device(buf), engine.to_device(offs))
+    t, o, f = t.cpu().numpy(), as_u64(o), f.cpu().numpy()
+    return [bytes(t[int(o[k]):int(o[k + 1])]) for k in range(len(docs))], f
+
+
+def test_normalize_en_matches_python(engine):
+    rng = np.random.Generator(np.random.PCG64(11))
+    ws = [9, 10, 11, 12, 13, 28, 29, 30, 31, 32]
+    docs = []
+    for _ in range(3000):
+        n = int(rng.integers(0, 400))
+        kind = rng.random(n)
+        c = np.where(kind < 0.25, rng.choice(ws, n), np.where(kind < 0.45, rng.integers(33, 127, n), rng.integers(1, 128, n)))
+        docs.append(bytes(c.astype(np.uint8)))
+    docs += [b"", b" ", b"!!!", b" \t\n", b"a", b" a ", b"A" * 64, b" " * 64 + b"x", b"x" + b" " * 63 + b" " * 64 + b"Y!",
+             b"," * 63 + b" " + b"," * 64 + b"z", b"a" + b"," * 200 + b"b", b"a " + b"," * 200 + b" b", b"\x1c\x1d\x1e\x1f",
+             b"a\x00b", b"Hello,  World!  ", bytes(range(1, 128)) * 3]
+    got, flags = _run(engine, docs)
+    assert not flags.any()
+    for d, g in zip(docs, got):
+        assert g == hostio.normalize_text(d.decode("ascii")).encode("ascii"), d
+
+
+def test_non_ascii_documents_are_flagged_not_touched(engine):
+    docs = ["Plain ASCII, here.", "naïve café", "", "中文 文档", "x" * 200 + "é", "Tail  OK!"]
+    got, flags = _run(engine, docs)
+    assert flags.tolist() == [0, 1, 0, 1, 1, 0]
+    assert got == [b"plain ascii here", b"", b"", b"", b"", b"tail ok"]
+
+
+def test_long_document_and_full_pipeline_equivalence(engine):
+    """normalise on device + signatures == signatures of the Python-normalised text"""
+    from oracle import ref_c as RC
+    rng = np.random.Generator(np.random.PCG64(12))
+    words = ["The", "QUICK,", "brown;", "fox", "jumps!", "over", "(the)", "lazy", "dog.", "\t", "\n\n", "  "]
+    docs = [" ".join(rng.choice(words, int(rng.integers(0, 3000)))) for _ in range(40)]
+    buf, offs = pack_texts(docs)
+    t, o, f = engine.normalize_en(engine.to_device(buf), engine.to_device(offs))
+    sig = engine.signatures(t, o).cpu().numpy().view(np.uint32)
+    nbuf, noffs = pack_texts([hostio.normalize_text(d) for d in docs])
+    exp = RC.signatures(nbuf, noffs)
+    assert (sig == exp).all()

@@ -145,3 +145,37 @@ def test_random_roundtrip_native_vs_python(tmp_path):
     for norm in (False, True):
         _same(hostio.read_jsonl_shard(str(p), "text", "doc_id", norm, "raise", True),
               hostio.read_jsonl_shard(str(p), "text", "doc_id", norm, "raise", False))
+
+
+def test_parquet_shard_reader_matches_row_path(tmp_path):
+    """Arrow-buffer ingest == the per-row Python path (nulls, empty, non-ASCII, several row groups)"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from map_neo_amd import hostio
+    rng = np.random.Generator(np.random.PCG64(8))
+    pool = ["Hello,  World!", None, "naïve Café  x", "", "  ALL caps\tHERE ", "中文文档", "a" * 300, "x\x1cy", "😀 ok"]
+    contents = [pool[int(i)] for i in rng.integers(0, len(pool), 500)]
+    ids = [None if i % 50 == 7 else f"d{i}" for i in range(500)]
+    path = str(tmp_path / "s.parquet")
+    pq.write_table(pa.table({"doc_id": ids, "raw_content": contents, "n": list(range(500))}), path, row_group_size=64)
+    for norm in (False, True):
+        r = hostio.read_parquet_shard(path, "raw_content", "doc_id", normalize_en=norm)
+        assert r["ids"] == ids
+        exp_cand = [i for i, c in enumerate(contents) if c is not None]
+        assert r["cand"].tolist() == exp_cand
+        docs = {}
+        for pos, k in enumerate(r["ready"].tolist()):
+            docs[k] = bytes(r["text"][int(r["offsets"][pos]):int(r["offsets"][pos + 1])]).decode("utf8")
+        raw = {}
+        for pos, k in enumerate(r["raw"].tolist()):
+            raw[k] = bytes(r["raw_text"][int(r["raw_offsets"][pos]):int(r["raw_offsets"][pos + 1])]).decode("utf8")
+        assert sorted(list(docs) + list(raw)) == list(range(len(exp_cand)))
+        for k, i in enumerate(exp_cand):
+            if k in docs:
+                assert docs[k] == (hostio.normalize_text(contents[i]) if norm else contents[i])
+                assert not norm or not contents[i].isascii() or hostio._ftfy is not None
+            else:
+                assert norm and raw[k] == contents[i] and contents[i].isascii()
+    # absent column / non-string column: nothing to hash
+    assert len(hostio.read_parquet_shard(path, "missing", "doc_id")["cand"]) == 0
+    assert len(hostio.read_parquet_shard(path, "n", "doc_id")["cand"]) == 0
