@@ -180,11 +180,11 @@ int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint6
  * A 64-bit content hash (truncated to key_bits; pass 64) only picks the table slot; units whose
  * hash collides with a different unit's get first_of[u] = u provisionally and are listed in
  * coll_idx / *n_coll (device u64) for exact resolution by the caller.
- * Workspaces: key_scratch u64[n_units]; tab_key u64[tab_size], tab_rep u32[tab_size], tab_size a
- * power of two >= 2*n_units.  avg_unit_bytes picks thread-per-unit (< 256) or wave-per-unit. */
+ * Workspaces: key_scratch u64[n_units]; table u64[tab_size], tab_size a power of two
+ * >= 2*n_units.  avg_unit_bytes picks thread-per-unit (< 256) or wave-per-unit hashing. */
 int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
-                    uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* tab_key, uint32_t* tab_rep,
-                    uint64_t tab_size, uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
+                    uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
+                    uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
 
 /* EN normalisation of pure-ASCII documents on the device.  Replaces
  * normalize_text EN:31-40 (fix_text/NFC: identity on clean ASCII; lower; delete

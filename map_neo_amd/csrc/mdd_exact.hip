@@ -9,7 +9,8 @@
 // known), so grouping on the bytes themselves gives the same groups.  A 64-bit content hash only
 // selects the hash-table slot; membership is decided by comparing the bytes, and units whose
 // hash collides with a different unit's are reported for exact resolution by the caller.
-// HBM-bound: every unit's bytes are read twice (hash, verify) plus ~2 random 8-byte atomics.
+// HBM-bound: every unit's bytes are read once to hash (duplicates once more to verify) plus one
+// random 8-byte atomic and one random 8-byte read per unit.
 #include "mdd_common.h"
 
 namespace {
@@ -67,16 +68,23 @@ __global__ void __launch_bounds__(256) exact_hash_wave_kernel(const uint64_t* t6
     if (lane == 0) key[u] = finish_key(sum, len, key_bits);
 }
 
-__global__ void __launch_bounds__(256) exact_insert_kernel(const uint64_t* key, uint64_t n, unsigned long long* tab_key,
-                                                           uint32_t* tab_rep, uint64_t tab_mask) {
+// One 8-byte table entry = (tag << 32 | smallest unit index seen), tag = high half of the key, slot
+// from its low bits: ONE random atomic per unit in the common case (the claim), and one random
+// read per unit in the link pass.  Every device atomic is a full memory transaction here, so
+// the table passes are bound by random-line HBM traffic and halving the transactions halves them.
+constexpr unsigned long long EMPTY = ~0ULL;
+
+__global__ void __launch_bounds__(256) exact_insert_kernel(const uint64_t* key, uint64_t n, unsigned long long* tab, uint64_t tab_mask) {
     uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n) return;
-    unsigned long long k = key[u];
-    uint64_t slot = mix64(k) & tab_mask;
+    uint64_t k = key[u];
+    unsigned long long val = (k & 0xFFFFFFFF00000000ULL) | (uint32_t)u;
+    uint64_t slot = k & tab_mask;
     for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: the table is at most half full
-        unsigned long long cur = atomicCAS(&tab_key[slot], 0ULL, k);
-        if (cur == 0ULL || cur == k) {
-            atomicMin(&tab_rep[slot], (uint32_t)u);
+        unsigned long long cur = atomicCAS(&tab[slot], EMPTY, val);
+        if (cur == EMPTY) return;
+        if ((cur >> 32) == (val >> 32)) {
+            if (cur > val) atomicMin(&tab[slot], val);
             return;
         }
         slot = (slot + 1) & tab_mask;
@@ -84,21 +92,21 @@ __global__ void __launch_bounds__(256) exact_insert_kernel(const uint64_t* key, 
 }
 
 __global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, const uint64_t* ubeg, const uint64_t* uend,
-                                                         const uint64_t* key, uint64_t n, const unsigned long long* tab_key,
-                                                         const uint32_t* tab_rep, uint64_t tab_mask, uint32_t* first_of,
-                                                         uint64_t* coll_idx, uint64_t coll_cap, unsigned long long* n_coll) {
+                                                         const uint64_t* key, uint64_t n, const unsigned long long* tab,
+                                                         uint64_t tab_mask, uint32_t* first_of, uint64_t* coll_idx,
+                                                         uint64_t coll_cap, unsigned long long* n_coll) {
     uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n) return;
-    unsigned long long k = key[u];
-    uint64_t slot = mix64(k) & tab_mask;
+    uint64_t k = key[u];
+    uint64_t slot = k & tab_mask;
     uint32_t rep = (uint32_t)u;
     for (uint64_t probe = 0; probe <= tab_mask; probe++) {
-        unsigned long long cur = tab_key[slot];
-        if (cur == k) {
-            rep = tab_rep[slot];
+        unsigned long long cur = tab[slot];
+        if (cur == EMPTY) break;
+        if ((cur >> 32) == (k >> 32)) {
+            rep = (uint32_t)cur;
             break;
         }
-        if (cur == 0ULL) break;
         slot = (slot + 1) & tab_mask;
     }
     uint32_t out = (uint32_t)u;
@@ -128,17 +136,15 @@ __global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, co
 }  // namespace
 
 extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
-                               uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* tab_key,
-                               uint32_t* tab_rep, uint64_t tab_size, uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap,
-                               uint64_t* n_coll) {
+                               uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
+                               uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll) {
     REQUIRE(ctx && n_coll, "mdd_exact_group: NULL argument");
     REQUIRE(key_bits >= 1 && key_bits <= 64, "mdd_exact_group: key_bits=%d outside [1,64]", key_bits);
     REQUIRE(n_units <= 0xFFFFFFFEull, "mdd_exact_group: n_units=%llu exceeds 2^32-2", (unsigned long long)n_units);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(n_coll, 0, sizeof(uint64_t), ctx->stream));
     if (n_units == 0) return MDD_OK;
-    REQUIRE(text && ubeg && uend && key_scratch && tab_key && tab_rep && first_of && (coll_cap == 0 || coll_idx),
-            "mdd_exact_group: NULL buffer");
+    REQUIRE(text && ubeg && uend && key_scratch && table && first_of && (coll_cap == 0 || coll_idx), "mdd_exact_group: NULL buffer");
     REQUIRE((reinterpret_cast<uintptr_t>(text) & 7u) == 0, "mdd_exact_group: text must be 8-byte aligned");
     REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_units,
             "mdd_exact_group: tab_size=%llu must be a power of two >= 2*n_units", (unsigned long long)tab_size);
@@ -152,14 +158,13 @@ extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t
                            n_units, key_bits, key_scratch);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(tab_key, 0, sizeof(uint64_t) * tab_size, ctx->stream));
-    HIP_TRY(hipMemsetAsync(tab_rep, 0xFF, sizeof(uint32_t) * tab_size, ctx->stream));
+    HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
     unsigned g = grid_for(n_units, 256);
     hipLaunchKernelGGL(exact_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key_scratch, n_units,
-                       reinterpret_cast<unsigned long long*>(tab_key), tab_rep, tab_size - 1);
+                       reinterpret_cast<unsigned long long*>(table), tab_size - 1);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(exact_link_kernel, dim3(g), dim3(256), 0, ctx->stream, t64, ubeg, uend, key_scratch, n_units,
-                       reinterpret_cast<const unsigned long long*>(tab_key), tab_rep, tab_size - 1, first_of, coll_idx, coll_cap,
+                       reinterpret_cast<const unsigned long long*>(table), tab_size - 1, first_of, coll_idx, coll_cap,
                        reinterpret_cast<unsigned long long*>(n_coll));
     HIP_TRY(hipGetLastError());
     return MDD_OK;

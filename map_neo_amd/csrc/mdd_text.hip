@@ -9,7 +9,7 @@
 //   re.sub(r"\s+", " ")                 every remaining whitespace run becomes one space
 // ASCII whitespace as Python's str.isspace / re \s see it: 0x09-0x0D, 0x1C-0x1F, 0x20.
 // Documents holding any byte >= 0x80 are flagged and produce no output: the caller runs the
-// Python steps on exactly those.  One wave per document, 64 bytes per step; the output position of
+// Python steps on exactly those.  One wave per document, 64 bytes per step (4 steps per load batch); the output position of
 // every byte comes from ballots + popcounts, so there is no scan and no LDS.  HBM-bound: the text
 // is read twice (count, write) and the normalised text written once.
 #include "mdd_common.h"
@@ -35,30 +35,38 @@ __global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict_
         const uint64_t o = WRITE ? out_offs[d] : 0;
         uint64_t cnt = 0;
         bool prev_ws = false, seen = false, bad = false;  // wave-uniform carries between 64-byte steps
-        for (uint64_t p = b; p < e; p += 64) {
-            const uint64_t i = p + lane;
-            const bool in = i < e;
-            uint32_t c = in ? text[i] : 0u;
-            if (!WRITE && __ballot(c >= 128u)) {
+        for (uint64_t p = b; p < e && !bad; p += 256) {
+            uint32_t cc[4];  // four independent loads in flight: the loop is latency-bound otherwise
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = p + 64 * j + lane;
+                cc[j] = i < e ? text[i] : 0u;
+            }
+            if (!WRITE && __ballot((cc[0] | cc[1] | cc[2] | cc[3]) >= 128u)) {
                 bad = true;
                 break;
             }
-            const bool keep = in && !is_punct(c);
-            const bool ws = is_space(c);
-            const uint64_t K = __ballot(keep), W = __ballot(keep && ws), N = K & ~W;
-            const bool is_n = (N >> lane) & 1;
-            const uint64_t pk = K & lt;
-            const bool pws = pk ? ((W >> (63 - __builtin_clzll(pk))) & 1) : prev_ws;  // previous kept byte is whitespace
-            const bool sp = is_n && pws && (seen || (N & lt));                          // a space precedes this byte
-            const uint64_t S = __ballot(sp);
-            if (WRITE && is_n) {
-                uint64_t pos = o + cnt + __builtin_popcountll(N & lt) + __builtin_popcountll(S & lt);
-                if (sp) out_text[pos++] = ' ';
-                out_text[pos] = (uint8_t)((c - 65u <= 25u) ? c + 32u : c);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t c = cc[j];
+                const bool in = p + 64 * j + lane < e;
+                const bool keep = in && !is_punct(c);
+                const bool ws = is_space(c);
+                const uint64_t K = __ballot(keep), W = __ballot(keep && ws), N = K & ~W;
+                const bool is_n = (N >> lane) & 1;
+                const uint64_t pk = K & lt;
+                const bool pws = pk ? ((W >> (63 - __builtin_clzll(pk))) & 1) : prev_ws;  // previous kept byte is whitespace
+                const bool sp = is_n && pws && (seen || (N & lt));                          // a space precedes this byte
+                const uint64_t S = __ballot(sp);
+                if (WRITE && is_n) {
+                    uint64_t pos = o + cnt + __builtin_popcountll(N & lt) + __builtin_popcountll(S & lt);
+                    if (sp) out_text[pos++] = ' ';
+                    out_text[pos] = (uint8_t)((c - 65u <= 25u) ? c + 32u : c);
+                }
+                cnt += __builtin_popcountll(N) + __builtin_popcountll(S);
+                if (K) prev_ws = (W >> (63 - __builtin_clzll(K))) & 1;
+                seen = seen || N;
             }
-            cnt += __builtin_popcountll(N) + __builtin_popcountll(S);
-            if (K) prev_ws = (W >> (63 - __builtin_clzll(K))) & 1;
-            seen = seen || N;
         }
         if (!WRITE && lane == 0) {
             out_len[d] = bad ? 0 : cnt;

@@ -4,9 +4,12 @@
   exact_document_dedup  <- Exact_Document_Deduplication/exact_document_deduplication.py:16-18
   paragraph_dedup       <- Paragraph_Deduplication/paragraph.py:15-30
   exact_substr_dedup    <- Exact_Substring_Deduplication/exact_substr_dedup.py:34-47,55-95
-The GPU does the grouping (hash every unit, bucket, verify the bytes); cutting the text into
-units and re-assembling the survivors is vectorised numpy on the host.  The reference groups
-on SHA-256 digests; equal digest <=> equal bytes, so the groups are the same."""
+The `*_packed` functions work on a packed corpus resident in HBM (uint8 text with MDD_TEXT_PAD
+spare bytes + int64 offsets[n+1], documents in the order that defines "first") and keep every
+intermediate on the device: cutting the text into units, the grouping (HIP), marking and
+compacting the survivors (torch index plumbing on the same stream).  The list-level wrappers
+pack, call them and decode.  The reference groups on SHA-256 digests; equal digest <=> equal
+bytes, so the groups are the same."""
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
@@ -14,13 +17,42 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .minhash import Engine, as_u32, pack_texts
+from .minhash import Engine, pack_texts, padded_size
 
 
-def _group(eng: Engine, buf: np.ndarray, ubeg: np.ndarray, uend: np.ndarray, key_bits: int = 64) -> np.ndarray:
-    first = eng.exact_group(eng.to_device(buf), eng.to_device(ubeg.astype(np.uint64)), eng.to_device(uend.astype(np.uint64)),
-                            key_bits, text_host=buf)
-    return as_u32(first)
+def _arange_like(t: torch.Tensor, n: int) -> torch.Tensor:
+    return torch.arange(n, dtype=torch.int64, device=t.device)
+
+
+def _is_first(eng: Engine, text, ubeg, uend, key_bits: int) -> torch.Tensor:
+    """bool [n_units]: unit is the first (lowest index) of its group of identical units"""
+    if ubeg.numel() >= 1 << 31:
+        raise ValueError(f"{ubeg.numel()} units in one call: split the corpus (limit 2^31 - 1)")
+    first = eng.exact_group(text, ubeg.contiguous(), uend.contiguous(), key_bits)
+    return first == torch.arange(ubeg.numel(), dtype=torch.int32, device=first.device)   # u32 bits; n_units < 2^31 compares equal
+
+
+def _compact(text: torch.Tensor, total: int, offs: torch.Tensor, keep_byte: torch.Tensor, keep_doc: torch.Tensor):
+    """Packed corpus of the kept bytes of the kept documents -> (text', offsets', kept document indices)"""
+    csum = torch.zeros(total + 1, dtype=torch.int64, device=text.device)
+    torch.cumsum(keep_byte, 0, out=csum[1:])
+    doc_len = csum[offs[1:]] - csum[offs[:-1]]
+    docs = torch.nonzero(keep_doc).flatten()
+    doc_keep_byte = keep_byte & torch.repeat_interleave(keep_doc, offs[1:] - offs[:-1], output_size=total)
+    body = text[:total][doc_keep_byte]
+    out = torch.zeros(padded_size(body.numel()), dtype=torch.uint8, device=text.device)
+    out[: body.numel()] = body
+    new_offs = torch.zeros(docs.numel() + 1, dtype=torch.int64, device=text.device)
+    torch.cumsum(doc_len[docs], 0, out=new_offs[1:])
+    return out, new_offs, docs
+
+
+# ------------------------------------------------------------------------------------------
+# exact document dedup
+# ------------------------------------------------------------------------------------------
+def exact_document_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, key_bits: int = 64) -> torch.Tensor:
+    """bool [n_docs]: document is the first with its content (EXD:17 dropDuplicates)"""
+    return _is_first(eng, text, offs[:-1], offs[1:], key_bits)
 
 
 def exact_document_dedup(eng: Engine, contents: Sequence[Optional[str]], key_bits: int = 64) -> np.ndarray:
@@ -32,92 +64,138 @@ def exact_document_dedup(eng: Engine, contents: Sequence[Optional[str]], key_bit
         keep[nulls[0]] = True
     if idx:
         buf, offs = pack_texts([contents[i] for i in idx])
-        first = _group(eng, buf, offs[:-1], offs[1:], key_bits)
-        keep[np.asarray(idx)[first == np.arange(len(idx), dtype=np.uint32)]] = True
+        k = exact_document_dedup_packed(eng, eng.to_device(buf), eng.to_device(offs), key_bits)
+        keep[np.asarray(idx)[k.cpu().numpy()]] = True
     return keep
 
 
-def _count_cp(buf: np.ndarray, beg: np.ndarray, end: np.ndarray) -> np.ndarray:
-    """code points in each byte range (bytes that are not utf-8 continuation bytes)"""
-    start = ((buf & 0xC0) != 0x80).astype(np.int64)
-    cs = np.concatenate([[0], np.cumsum(start)])
-    return cs[end] - cs[beg]
+# ------------------------------------------------------------------------------------------
+# paragraph dedup
+# ------------------------------------------------------------------------------------------
+def paragraph_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, min_len: int = 20, key_bits: int = 64):
+    """Documents in (id, then input) order.  Returns (text', offsets', kept document indices):
+    every paragraph ("\\n"-separated, PAR:16-17) that already occurred earlier -- in an earlier
+    document or earlier in the same one -- is dropped (PAR:18-23), the survivors of a document are
+    re-joined with "\\n" (PAR:26-27), documents left without a paragraph or with fewer than
+    min_len code points are dropped (PAR:29)."""
+    dev = text.device
+    nd = offs.numel() - 1
+    total = int(offs[-1].item()) if nd > 0 else 0
+    if nd <= 0:
+        return torch.zeros(padded_size(0), dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), \
+            torch.zeros(0, dtype=torch.int64, device=dev)
+    body = text[:total]
+    nl = torch.nonzero(body == 10).flatten()                                  # 0x0A never occurs inside a multi-byte code point
+    doc_of_nl = torch.searchsorted(offs, nl, right=True) - 1
+    nl_before = torch.searchsorted(nl, offs[:-1])                             # newlines before each document
+    n_units = nd + nl.numel()
+    # unit index: first paragraph of document d = nl_before[d] + d; the paragraph after newline j = j + doc_of_nl[j] + 1
+    d_idx = _arange_like(offs, nd)
+    first_unit = nl_before + d_idx
+    after_nl = _arange_like(offs, nl.numel()) + doc_of_nl + 1
+    ubeg = torch.empty(n_units, dtype=torch.int64, device=dev)
+    uend = torch.empty(n_units, dtype=torch.int64, device=dev)
+    doc_of_unit = torch.empty(n_units, dtype=torch.int64, device=dev)
+    ubeg[first_unit] = offs[:-1]
+    ubeg[after_nl] = nl + 1
+    uend[after_nl - 1] = nl
+    last_unit = torch.cat([first_unit[1:], torch.tensor([n_units], dtype=torch.int64, device=dev)]) - 1
+    uend[last_unit] = offs[1:]
+    doc_of_unit[first_unit] = d_idx
+    doc_of_unit[after_nl] = doc_of_nl
+    keep_unit = _is_first(eng, text, ubeg, uend, key_bits)
+    # first kept paragraph of every document: it is written without the newline in front of it
+    kept_units = torch.nonzero(keep_unit).flatten()
+    kd = doc_of_unit[kept_units]
+    n_kept = torch.zeros(nd, dtype=torch.int64, device=dev).index_add_(0, kd, torch.ones_like(kd))
+    is_first_kept = torch.ones_like(kept_units, dtype=torch.bool)
+    if kept_units.numel() > 1:
+        is_first_kept[1:] = kd[1:] != kd[:-1]
+    start = ubeg[kept_units] - (~is_first_kept).to(torch.int64)               # take the "\n" that precedes the paragraph along
+    diff = torch.zeros(total + 1, dtype=torch.int32, device=dev)
+    one = torch.ones(kept_units.numel(), dtype=torch.int32, device=dev)
+    diff.index_add_(0, start, one)
+    diff.index_add_(0, uend[kept_units], -one)
+    keep_byte = torch.cumsum(diff[:-1], 0) > 0
+    del diff
+    keep_doc = n_kept > 0
+    if min_len > 0:
+        starts = torch.zeros(total + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(keep_byte & ((body & 0xC0) != 0x80), 0, out=starts[1:])
+        keep_doc &= (starts[offs[1:]] - starts[offs[:-1]]) >= min_len
+    return _compact(text, total, offs, keep_byte, keep_doc)
+
+
+def _decode(out_text, out_offs) -> List[str]:
+    t, o = out_text.cpu().numpy().tobytes(), out_offs.cpu().numpy()
+    return [t[int(o[k]):int(o[k + 1])].decode("utf8") for k in range(len(o) - 1)]
 
 
 def paragraph_dedup(eng: Engine, rows: Sequence[Tuple[object, Optional[str]]], min_len: int = 20,
                     key_bits: int = 64) -> List[Tuple[object, str]]:
-    """(id, text) per surviving document, sorted by id.  Rows must carry unique, mutually comparable ids."""
+    """(id, text) per surviving document, sorted by id.  Ids must be unique and mutually comparable
+    (the reference would merge the rows of a repeated id, PAR:26)."""
     rows = sorted(((rid, c) for rid, c in rows if c is not None), key=lambda r: r[0])
     if not rows:
         return []
     buf, offs = pack_texts([c for _, c in rows])
-    total = int(offs[-1])
-    nl = np.flatnonzero(buf[:total] == 10).astype(np.uint64)                # 0x0A never occurs inside a multi-byte code point
-    doc_of_nl = np.searchsorted(offs, nl, side="right") - 1
-    # unit boundaries: every document start and every byte after a newline
-    ubeg = np.concatenate([offs[:-1], nl + 1])
-    uend = np.concatenate([offs[1:], nl])                                    # placeholder; fixed below after sorting
-    order = np.argsort(ubeg, kind="stable")
-    ubeg = ubeg[order]
-    # a unit ends at the next newline or at its document's end, whichever comes first
-    doc_of_unit = np.concatenate([np.arange(len(rows)), doc_of_nl])[order]
-    nxt = np.searchsorted(nl, ubeg, side="left")
-    next_nl = np.where(nxt < len(nl), nl[np.minimum(nxt, max(len(nl) - 1, 0))] if len(nl) else 0, np.uint64(total))
-    uend = np.minimum(next_nl if len(nl) else np.full(len(ubeg), total, np.uint64), offs[doc_of_unit + 1])
-    # units are in (document order = id order, pos) order, so "smallest unit index" == PAR's row_number() == 1
-    first = _group(eng, buf, ubeg, uend, key_bits)
-    keep = first == np.arange(len(ubeg), dtype=np.uint32)
-    out = []
-    kb, ke, kd = ubeg[keep], uend[keep], doc_of_unit[keep]
-    starts = np.searchsorted(kd, np.arange(len(rows)), side="left")
-    ends = np.searchsorted(kd, np.arange(len(rows)), side="right")
-    raw = buf.tobytes()
-    for d, (rid, _) in enumerate(rows):
-        if starts[d] == ends[d]:
-            continue                                                         # no surviving paragraph: the document disappears
-        text = b"\n".join(raw[int(kb[k]):int(ke[k])] for k in range(starts[d], ends[d])).decode("utf8")
-        if min_len <= 0 or len(text) >= min_len:
-            out.append((rid, text))
-    return out
+    t, o, docs = paragraph_dedup_packed(eng, eng.to_device(buf), eng.to_device(offs), min_len, key_bits)
+    return [(rows[d][0], s) for d, s in zip(docs.cpu().tolist(), _decode(t, o))]
+
+
+# ------------------------------------------------------------------------------------------
+# exact substring dedup
+# ------------------------------------------------------------------------------------------
+def exact_substr_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, duplicate_len: int = 50,
+                              min_length: int = 20, key_bits: int = 64):
+    """Documents in input order (SUB:75 zipWithIndex).  Returns (text', offsets', kept document
+    indices): every window of duplicate_len code points starting at offsets
+    range(len - duplicate_len) (SUB:38) that already occurred at a smaller (document, offset) has
+    its code points deleted (SUB:44-47,58-67); documents left with fewer than min_length code
+    points are dropped (SUB:90)."""
+    dev = text.device
+    nd = offs.numel() - 1
+    total = int(offs[-1].item()) if nd > 0 else 0
+    if nd <= 0:
+        return torch.zeros(padded_size(0), dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), \
+            torch.zeros(0, dtype=torch.int64, device=dev)
+    body = text[:total]
+    is_start = (body & 0xC0) != 0x80
+    cp_pos = torch.nonzero(is_start).flatten()                                 # byte offset of every code point
+    n_cp = cp_pos.numel()
+    cp_end_of_doc = torch.searchsorted(cp_pos, offs[1:])                       # code points before each document's end
+    doc_of_cp = torch.searchsorted(offs, cp_pos, right=True) - 1
+    g = _arange_like(offs, n_cp)
+    wg = torch.nonzero((g + duplicate_len) < cp_end_of_doc[doc_of_cp]).flatten()
+    del doc_of_cp, g
+    gone = torch.zeros(n_cp, dtype=torch.bool, device=dev)
+    if wg.numel():
+        ubeg = cp_pos[wg]
+        uend = cp_pos[wg + duplicate_len]                                      # in range: wg + duplicate_len < the document's last code point + 1
+        dup = ~_is_first(eng, text, ubeg, uend, key_bits)
+        del ubeg, uend
+        dw = wg[dup]
+        diff = torch.zeros(n_cp + 1, dtype=torch.int32, device=dev)
+        one = torch.ones(dw.numel(), dtype=torch.int32, device=dev)
+        diff.index_add_(0, dw, one)
+        diff.index_add_(0, dw + duplicate_len, -one)
+        gone = torch.cumsum(diff[:-1], 0) > 0                                  # code points covered by a removed window
+        del diff
+    cp_of_byte = torch.cumsum(is_start, 0) - 1
+    keep_byte = ~gone[cp_of_byte] if n_cp else torch.zeros(total, dtype=torch.bool, device=dev)
+    del cp_of_byte
+    kept_cp = torch.zeros(n_cp + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(~gone, 0, out=kept_cp[1:])
+    cp_beg_of_doc = torch.searchsorted(cp_pos, offs[:-1])
+    keep_doc = (kept_cp[cp_end_of_doc] - kept_cp[cp_beg_of_doc]) >= min_length
+    return _compact(text, total, offs, keep_byte, keep_doc)
 
 
 def exact_substr_dedup(eng: Engine, rows: Sequence[Tuple[Optional[str], object]], duplicate_len: int = 50,
                        min_length: int = 20, key_bits: int = 64) -> List[Tuple[object, str]]:
     """(ori_doc_id, cleaned text) for documents that keep at least min_length characters."""
-    texts = [t for t, _ in rows]
-    buf, offs = pack_texts(texts)
-    total = int(offs[-1])
-    is_start = (buf[:total] & 0xC0) != 0x80
-    cp_pos = np.flatnonzero(is_start).astype(np.uint64)                       # byte offset of every code point
-    cp_pos_ext = np.concatenate([cp_pos, [np.uint64(total)]])
-    doc_cp_beg = np.searchsorted(cp_pos, offs[:-1], side="left")             # first code point index of each document
-    doc_cp_end = np.searchsorted(cp_pos, offs[1:], side="left")
-    n_cp = len(cp_pos)
-    doc_of_cp = np.repeat(np.arange(len(texts)), doc_cp_end - doc_cp_beg)
-    g = np.arange(n_cp)
-    # window at code point g is hashed iff g - doc_beg < len - duplicate_len  (SUB:37 range(len(text) - duplicate_len))
-    valid = (g + duplicate_len) < doc_cp_end[doc_of_cp] if n_cp else np.zeros(0, bool)
-    wg = g[valid]
-    removed_cp = np.zeros(n_cp + 1, dtype=np.int64)
-    if len(wg):
-        ubeg = cp_pos[wg]
-        uend = cp_pos_ext[wg + duplicate_len]
-        first = _group(eng, buf, ubeg, uend, key_bits)
-        dup = first != np.arange(len(wg), dtype=np.uint32)                   # every occurrence but the first (lowest (doc, offset))
-        np.add.at(removed_cp, wg[dup], 1)
-        np.add.at(removed_cp, wg[dup] + duplicate_len, -1)
-    gone = np.cumsum(removed_cp[:-1]) > 0                                    # code points covered by a removed window
-    out = []
-    raw = buf
-    for d, (_t, ori) in enumerate(rows):
-        b, e = int(doc_cp_beg[d]), int(doc_cp_end[d])
-        if gone[b:e].any():
-            keep_cp = ~gone[b:e]
-            byte_keep = np.repeat(keep_cp, np.diff(cp_pos_ext[b:e + 1]).astype(np.int64))
-            text = raw[int(offs[d]):int(offs[d + 1])][byte_keep].tobytes().decode("utf8")
-            n_chars = int(keep_cp.sum())
-        else:
-            text, n_chars = texts[d], e - b
-        if n_chars >= min_length:
-            out.append((ori, text))
-    return out
+    if not rows:
+        return []
+    buf, offs = pack_texts([t for t, _ in rows])
+    t, o, docs = exact_substr_dedup_packed(eng, eng.to_device(buf), eng.to_device(offs), duplicate_len, min_length, key_bits)
+    return [(rows[d][1], s) for d, s in zip(docs.cpu().tolist(), _decode(t, o))]

@@ -195,8 +195,7 @@ class Engine:
         tab_size = 2
         while tab_size < 2 * max(1, n_rec):
             tab_size *= 2
-        tab_key = self.empty(tab_size, torch.int64)
-        tab_rep = self.empty(tab_size, torch.int32)
+        table = self.empty(tab_size, torch.int64)
         eu = self.empty(max(1, n_rec), torch.int32)
         ev = self.empty(max(1, n_rec), torch.int32)
         coll_cap = max(1024, n_rec)
@@ -254,13 +253,12 @@ class Engine:
         while tab_size < 2 * n:
             tab_size *= 2
         key = self.empty(n, torch.int64)
-        tab_key = self.empty(tab_size, torch.int64)
-        tab_rep = self.empty(tab_size, torch.int32)
+        table = self.empty(tab_size, torch.int64)
         coll = self.empty(max(1024, n), torch.int64)
         cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
         _lib.check(self.L.mdd_exact_group(self.ctx, _ptr(text), _ptr(ubeg), _ptr(uend), n, total // n, key_bits, _ptr(key),
-                                          _ptr(tab_key), _ptr(tab_rep), tab_size, _ptr(first_of), _ptr(coll), coll.numel(),
-                                          _ptr(cnt)), "mdd_exact_group")
+                                          _ptr(table), tab_size, _ptr(first_of), _ptr(coll), coll.numel(), _ptr(cnt)),
+                   "mdd_exact_group")
         n_coll = int(cnt.item())
         if n_coll:
             idx = as_u64(coll[:n_coll]).astype(np.int64)

@@ -84,3 +84,22 @@ def test_exact_substr_dedup(engine, key_bits):
     exp = RX.exact_substr_dedup(rows, 50, 20)
     assert got == exp
     assert sum(len(t) for _, t in got) < sum(len(t) for t, _ in rows)
+
+
+def test_paragraph_and_substr_edge_cases(engine):
+    cases = [
+        [(1, "")], [(1, ""), (2, "")], [(1, "\n")], [(1, "\n\n\n"), (2, "\n")], [(1, "a\n"), (2, "\na")],
+        [(1, "same\nsame\nsame")], [(2, "x\ny"), (1, "y\nx")], [(1, "tail\n"), (2, "tail"), (3, "\ntail\n\n")],
+        [(1, "only one paragraph that is long enough to stay")], [(1, None), (2, None)], [],
+        [(1, "多字节\n多字节\nüber\n"), (2, "über\n多字节\nnew")],
+    ]
+    for rows in cases:
+        for min_len in (0, 3, 20):
+            assert exact.paragraph_dedup(engine, rows, min_len=min_len) == RX.paragraph_dedup(rows, min_len=min_len), (rows, min_len)
+    sub = [
+        [("", "a")], [("x" * 50, "a")], [("x" * 51, "a")], [("x" * 52, "a")], [("ab" * 60, "a"), ("ab" * 60, "b")],
+        [("é" * 120, "a")], [("0123456789" * 6, "a"), ("z" + "0123456789" * 6, "b"), ("0123456789" * 5 + "0", "c")], [],
+    ]
+    for rows in sub:
+        for dl, ml in ((50, 20), (5, 0), (50, 0)):
+            assert exact.exact_substr_dedup(engine, rows, dl, ml) == RX.exact_substr_dedup(rows, dl, ml), (rows, dl, ml)
