@@ -1,0 +1,93 @@
+"""Shared by the drop-ins of the EN pipeline's exact-match stages (exact_document_deduplication,
+paragraph, exact_substr_dedup): shard ingest into one packed corpus in HBM and gzip JSON-lines
+output.  The corpus of one invocation is held in host memory once and in HBM once."""
+from __future__ import annotations
+
+import gzip
+import json
+import multiprocessing as mp
+import os
+
+import numpy as np
+
+CONTENT_FIELD_NAME = "raw_content"          # EXD:4, PAR:12, SUB:17
+DOC_ID_FIELD_NAME = "doc_id"                # SUB:18, PAR:35
+
+
+def _parse(task):
+    path, content_field, id_field = task
+    from .. import hostio
+    r = hostio.read_jsonl_shard(path, content_field, id_field, normalize_en=False, on_error="skip")
+    return r["ids"], r["line_no"], r["cand"], r["text"], r["offsets"]
+
+
+def load_corpus(input_dir: str, workers: int, device: int = 0, content_field: str = CONTENT_FIELD_NAME,
+                id_field=DOC_ID_FIELD_NAME):
+    """-> dict: files, eng, text/offs (device, packed, documents in file-then-line order),
+    doc_file / doc_row (which file / physical line every document came from), doc_ids,
+    rows_per_file [(ids, line_no, cand)]"""
+    from .. import hostio
+    files = hostio.list_files(input_dir)
+    pool = mp.get_context("fork").Pool(max(1, workers))       # forked before this process touches the GPU
+    try:
+        parsed = pool.map(_parse, [(p, content_field, id_field) for p in files])
+    finally:
+        pool.close()
+        pool.join()
+    from ..minhash import Engine, padded_size
+    eng = Engine(device)
+    total = sum(int(t.size) for *_, t, _ in parsed)
+    buf = np.zeros(padded_size(total), dtype=np.uint8)
+    offs, doc_file, doc_row, doc_ids, per_file, base = [np.zeros(1, np.uint64)], [], [], [], [], 0
+    for fi, (ids, line_no, cand, text, o) in enumerate(parsed):
+        buf[base: base + text.size] = text
+        offs.append(o[1:] + np.uint64(base))
+        base += int(text.size)
+        doc_file.append(np.full(len(cand), fi, dtype=np.int64))
+        doc_row.append(line_no[cand].astype(np.int64) if len(cand) else np.zeros(0, np.int64))
+        doc_ids.extend(ids[i] for i in cand.tolist())
+        per_file.append((ids, line_no, cand))
+    return {"files": files, "eng": eng, "text": eng.to_device(buf), "offs": eng.to_device(np.concatenate(offs)),
+            "doc_file": np.concatenate(doc_file) if doc_file else np.zeros(0, np.int64),
+            "doc_row": np.concatenate(doc_row) if doc_row else np.zeros(0, np.int64), "doc_ids": doc_ids,
+            "rows_per_file": per_file, "workers": workers}
+
+
+def reorder_packed(text, offs, perm):
+    """Packed corpus with its documents permuted (device): document k of the result = document perm[k]"""
+    import torch
+    from ..minhash import padded_size
+    lens = (offs[1:] - offs[:-1])[perm]
+    new_offs = torch.zeros(perm.numel() + 1, dtype=torch.int64, device=text.device)
+    torch.cumsum(lens, 0, out=new_offs[1:])
+    total = int(new_offs[-1].item()) if perm.numel() else 0
+    src = torch.repeat_interleave(offs[:-1][perm] - new_offs[:-1], lens, output_size=total) + \
+        torch.arange(total, dtype=torch.int64, device=text.device)
+    out = torch.zeros(padded_size(total), dtype=torch.uint8, device=text.device)
+    out[:total] = text[src]
+    return out, new_offs
+
+
+def _write_part(task):
+    out_path, ids, raw, offs = task
+    with gzip.open(out_path, "wt", encoding="utf8", compresslevel=6) as f:
+        for k, rid in enumerate(ids):
+            row = {DOC_ID_FIELD_NAME: rid, CONTENT_FIELD_NAME: raw[int(offs[k]) - int(offs[0]): int(offs[k + 1]) - int(offs[0])].decode("utf8")}
+            f.write(json.dumps(row, ensure_ascii=False) + "\n")
+    return len(ids)
+
+
+def write_docs(output_dir: str, ids, text, offs, workers: int, docs_per_part: int = 100_000) -> int:
+    """gzip JSON lines {"doc_id", "raw_content"} (the two columns PAR:27-28 / SUB:92 keep), one part per 100k documents"""
+    os.makedirs(output_dir, exist_ok=True)
+    raw, o = text.cpu().numpy(), offs.cpu().numpy()
+    tasks = []
+    for p, k0 in enumerate(range(0, len(ids), docs_per_part)):
+        k1 = min(len(ids), k0 + docs_per_part)
+        tasks.append((os.path.join(output_dir, "part-%05d.json.gz" % p), ids[k0:k1], raw[int(o[k0]):int(o[k1])].tobytes(), o[k0:k1 + 1]))
+    if not tasks:
+        return 0
+    if workers <= 1 or len(tasks) == 1:
+        return sum(map(_write_part, tasks))
+    with mp.get_context("spawn").Pool(min(workers, len(tasks))) as pool:   # the parent holds a GPU context: never fork it
+        return sum(pool.map(_write_part, tasks))

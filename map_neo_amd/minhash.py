@@ -195,7 +195,8 @@ class Engine:
         tab_size = 2
         while tab_size < 2 * max(1, n_rec):
             tab_size *= 2
-        table = self.empty(tab_size, torch.int64)
+        tab_key = self.empty(tab_size, torch.int64)
+        tab_rep = self.empty(tab_size, torch.int32)
         eu = self.empty(max(1, n_rec), torch.int32)
         ev = self.empty(max(1, n_rec), torch.int32)
         coll_cap = max(1024, n_rec)

@@ -216,3 +216,69 @@ def test_stage_entry_point_parquet_device_normalisation(tmp_path, mini_docs):
     assert set(open(out / "removed_ids.txt").read().split()) == exp_removed
     assert ids[5] in set(open(out / "kept_ids.txt").read().split())
     assert s["n_hashed"] == n - 1 and len(exp_removed) > 0
+
+
+def _write_jsonl(path, rows, gz=False):
+    op = gzip.open if gz else open
+    with op(path, "wt", encoding="utf8") as f:
+        for r in rows:
+            f.write(json.dumps(r, ensure_ascii=False) + "\n")
+
+
+def _read_parts(d):
+    return [json.loads(l) for p in sorted(os.listdir(d)) for l in gzip.open(os.path.join(d, p), "rt", encoding="utf8")]
+
+
+def _en_stage_corpus():
+    rng = np.random.Generator(np.random.PCG64(31))
+    words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "naïve", "数据", "x"]
+    paras = [" ".join(rng.choice(words, int(rng.integers(3, 30)))) for _ in range(40)] + [""]
+    docs = ["\n".join(rng.choice(paras, int(rng.integers(1, 8)))) for _ in range(150)]
+    docs += [docs[int(i)] for i in rng.integers(0, 150, 30)]
+    ids = [f"d{int(i):04d}" for i in rng.permutation(len(docs))]
+    return [{"doc_id": i, "raw_content": t, "meta": k} for k, (i, t) in enumerate(zip(ids, docs))]
+
+
+def test_exact_document_deduplication_cli(tmp_path):
+    from oracle import ref_exact as RX
+    from map_neo_amd.cli import exact_document_deduplication as cli
+    rows = _en_stage_corpus()
+    rows[3]["raw_content"] = None
+    rows[100].pop("raw_content")
+    inp = tmp_path / "in"
+    inp.mkdir()
+    _write_jsonl(inp / "a.json", rows[:90])
+    _write_jsonl(inp / "b.json.gz", rows[90:], gz=True)
+    cli.main(["--input_dir", str(inp), "--output_dir", str(tmp_path / "o"), "--workers", "2"])
+    keep = RX.exact_document_dedup([r.get("raw_content") for r in rows])
+    assert _read_parts(tmp_path / "o") == [r for r, k in zip(rows, keep) if k]
+
+
+def test_paragraph_cli(tmp_path, capsys):
+    from oracle import ref_exact as RX
+    from map_neo_amd.cli import paragraph as cli
+    rows = _en_stage_corpus()
+    rows[5]["raw_content"] = None
+    inp = tmp_path / "in"
+    inp.mkdir()
+    _write_jsonl(inp / "a.json", rows[:70])
+    _write_jsonl(inp / "b.json", rows[70:])
+    cli.main(["--input_dir", str(inp), "--output_dir", str(tmp_path / "o"), "--workers", "2"])
+    exp = RX.paragraph_dedup([(r["doc_id"], r["raw_content"]) for r in rows], min_len=20)
+    assert _read_parts(tmp_path / "o") == [{"doc_id": i, "raw_content": t} for i, t in exp]
+    assert "after paragraph dedup: %d" % len(exp) in capsys.readouterr().out
+
+
+def test_exact_substr_dedup_cli(tmp_path, capsys):
+    from oracle import ref_exact as RX
+    from map_neo_amd.cli import exact_substr_dedup as cli
+    rows = _en_stage_corpus()
+    inp = tmp_path / "in"
+    inp.mkdir()
+    _write_jsonl(inp / "a.json", rows[:70])
+    _write_jsonl(inp / "b.json", rows[70:])
+    cli.main(["--input_dir", str(inp), "--output_dir", str(tmp_path / "o"), "--workers", "1"])
+    exp = RX.exact_substr_dedup([(r["raw_content"], r["doc_id"]) for r in rows], 50, 20)
+    assert _read_parts(tmp_path / "o") == [{"doc_id": i, "raw_content": t} for i, t in exp]
+    out = capsys.readouterr().out
+    assert "the number of docs is  %d" % len(rows) in out and "the number of deduped docs is  %d" % len(exp) in out
