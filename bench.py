@@ -91,6 +91,108 @@ def cpu_baseline(n_sample: int, mean_bytes: int, seed: int):
             "c_port_1core_docs_per_s": n_sample / dt_c, "n_removed_sample": int((labels != np.arange(n_sample)).sum())}
 
 
+def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
+    """Stages around MinHash in the EN pipeline on the bench corpus, text resident in
+    HBM: device EN normalisation, exact document dedup, paragraph dedup, exact substring dedup.  All HBM-bound:
+    each entry carries its algorithmic bytes / time against the 8 TB/s peak, and (with_cpu) the oracle
+    restatement of the reference's Spark job timed on one host core over a bounded sample."""
+    import torch
+
+    from map_neo_amd import exact
+    dev, n = eng.device, offsets.numel() - 1
+    HBM = 8000.0
+
+    def timed(fn, reps=2):
+        r = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, r
+
+    def docs_of(t, o, k):
+        o = o[: k + 1].cpu().numpy()
+        b = t[: int(o[-1])].cpu().numpy().tobytes()
+        return [b[int(o[i]):int(o[i + 1])].decode("utf8") for i in range(k)]
+
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(1)
+    r = torch.rand(text_bytes, device=dev, generator=g)
+    body = text[:text_bytes]
+    # un-normalised look: upper-case 1/8 of the letters, 1/16 of the spaces become commas
+    raw = text.clone()
+    rb = raw[:text_bytes]
+    rb.copy_(torch.where((body >= 97) & (body <= 122) & (r < 0.125), body - 32, body))
+    rb.copy_(torch.where((body == 32) & (r > 0.9375), torch.full_like(body, 44), rb))
+    ms, (nt, no, fl) = timed(lambda: eng.normalize_en(raw, offsets))
+    ob = int(no[-1].item())
+    out["normalize_en"] = {"ms": ms, "docs_per_s": n / ms * 1e3, "text_gb_per_s": text_bytes / ms / 1e6,
+                           "algorithmic_bytes": 2 * text_bytes + ob, "hbm_frac": (2 * text_bytes + ob) / ms / 1e6 / HBM}
+    if with_cpu:
+        from map_neo_amd import hostio
+        sample = docs_of(raw, offsets, 3000)
+        t0 = time.perf_counter()
+        ref = [hostio.normalize_text(d) for d in sample]
+        dt = time.perf_counter() - t0
+        assert ref == docs_of(nt, no, 3000)
+        out["normalize_en"]["cpu_python_docs_per_s_1core"] = len(sample) / dt
+    del raw, rb, nt, no, fl
+
+    ms, keep = timed(lambda: exact.exact_document_dedup_packed(eng, text, offsets))
+    out["exact_document_dedup"] = {"ms": ms, "docs_per_s": n / ms * 1e3, "text_gb_per_s": text_bytes / ms / 1e6,
+                                   "algorithmic_bytes": text_bytes + 28 * n, "hbm_frac": (text_bytes + 28 * n) / ms / 1e6 / HBM,
+                                   "n_removed": int((~keep).sum().item())}
+
+    # paragraphs: every 40th space becomes a newline
+    par = text.clone()
+    pb = par[:text_bytes]
+    pb.copy_(torch.where((body == 32) & (r < 0.025), torch.full_like(body, 10), body))
+    del r
+    ms, (pt, po, pd) = timed(lambda: exact.paragraph_dedup_packed(eng, par, offsets, 20))
+    n_par = n + int((pb == 10).sum().item())
+    out["paragraph_dedup"] = {"ms": ms, "docs_per_s": n / ms * 1e3, "text_gb_per_s": text_bytes / ms / 1e6, "paragraphs": n_par,
+                              "bytes_out": int(po[-1].item()), "docs_out": int(pd.numel()),
+                              "algorithmic_bytes": 2 * text_bytes + int(po[-1].item()) + 36 * n_par,
+                              "hbm_frac": (2 * text_bytes + int(po[-1].item()) + 36 * n_par) / ms / 1e6 / HBM}
+    if with_cpu:
+        from oracle import ref_exact
+        k = 20000
+        sample = docs_of(par, offsets, k)
+        t0 = time.perf_counter()
+        ref = ref_exact.paragraph_dedup(list(enumerate(sample)), 20)
+        dt = time.perf_counter() - t0
+        st, so, sd = exact.paragraph_dedup_packed(eng, par, offsets[: k + 1].contiguous(), 20)
+        assert [t for _, t in ref] == docs_of(st, so, sd.numel()) and [i for i, _ in ref] == sd.cpu().tolist()
+        out["paragraph_dedup"]["cpu_oracle_docs_per_s_1core"] = k / dt
+        out["paragraph_dedup"]["cpu_sample"] = "first %d docs, oracle/ref_exact.paragraph_dedup (hashlib sha256), %.1f s" % (k, dt)
+    del par, pb, pt, po, pd
+
+    # substring dedup: one call handles < 2^31 windows -> the first 600k documents (~1.3 G windows)
+    k = min(n, 600_000)
+    so = offsets[: k + 1].contiguous()
+    sb = int(so[-1].item())
+    ms, (st, so2, sd) = timed(lambda: exact.exact_substr_dedup_packed(eng, text, so, 50, 20), reps=1)
+    out["exact_substr_dedup"] = {"ms": ms, "docs": k, "docs_per_s": k / ms * 1e3, "text_gb_per_s": sb / ms / 1e6,
+                                 "windows_per_s": (sb - 50 * k) / ms * 1e3, "bytes_out": int(so2[-1].item()), "docs_out": int(sd.numel()),
+                                 "algorithmic_bytes": 2 * sb + int(so2[-1].item()) + 36 * (sb - 50 * k),
+                                 "hbm_frac": (2 * sb + int(so2[-1].item()) + 36 * (sb - 50 * k)) / ms / 1e6 / HBM}
+    if with_cpu:
+        from oracle import ref_exact
+        k = 1500
+        sample = docs_of(text, offsets, k)
+        t0 = time.perf_counter()
+        ref = ref_exact.exact_substr_dedup([(d, i) for i, d in enumerate(sample)], 50, 20)
+        dt = time.perf_counter() - t0
+        st, so2, sd = exact.exact_substr_dedup_packed(eng, text, offsets[: k + 1].contiguous(), 50, 20)
+        assert [t for _, t in ref] == docs_of(st, so2, sd.numel()) and [i for i, _ in ref] == sd.cpu().tolist()
+        out["exact_substr_dedup"]["cpu_oracle_docs_per_s_1core"] = k / dt
+        out["exact_substr_dedup"]["cpu_sample"] = "first %d docs, oracle/ref_exact.exact_substr_dedup (hashlib sha256 per window), %.1f s" % (k, dt)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +203,8 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=16000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the optional PCIe / pinned-host measurements")
+    ap.add_argument("--stages", action="store_true",
+                    help="also time the stages around MinHash (SURVEY 8(f) ranks 2-4) and report them under next_rows")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the multi-GPU path (RCCL all-to-all / all-gather) even with one rank")
     args = ap.parse_args()
@@ -272,6 +376,9 @@ def main():
         }
         if cpu is not None:
             res["cpu_baseline"] = cpu
+        if args.stages and world == 1:
+            del out
+            res["next_rows"] = stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=not args.no_cpu)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

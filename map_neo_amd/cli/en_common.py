@@ -56,15 +56,23 @@ def load_corpus(input_dir: str, workers: int, device: int = 0, content_field: st
 def reorder_packed(text, offs, perm):
     """Packed corpus with its documents permuted (device): document k of the result = document perm[k]"""
     import torch
+    from ..exact import _cumsum
     from ..minhash import padded_size
     lens = (offs[1:] - offs[:-1])[perm]
     new_offs = torch.zeros(perm.numel() + 1, dtype=torch.int64, device=text.device)
     torch.cumsum(lens, 0, out=new_offs[1:])
     total = int(new_offs[-1].item()) if perm.numel() else 0
-    src = torch.repeat_interleave(offs[:-1][perm] - new_offs[:-1], lens, output_size=total) + \
-        torch.arange(total, dtype=torch.int64, device=text.device)
     out = torch.zeros(padded_size(total), dtype=torch.uint8, device=text.device)
-    out[:total] = text[src]
+    if total:
+        # source byte of output byte i = i + shift(document of i); the shifts are laid down as differences at
+        # the document starts and prefix-summed (empty documents add their differences at the same position)
+        shift = offs[:-1][perm] - new_offs[:-1]
+        delta = torch.zeros(total + 1, dtype=torch.int64, device=text.device)
+        delta.index_add_(0, new_offs[:-1], torch.cat([shift[:1], shift[1:] - shift[:-1]]))
+        src = _cumsum(delta[:-1], torch.empty(total, dtype=torch.int64, device=text.device))
+        del delta
+        src += torch.arange(total, dtype=torch.int64, device=text.device)
+        out[:total] = text[src]
     return out, new_offs
 
 

@@ -20,6 +20,42 @@ import torch
 from .minhash import Engine, pack_texts, padded_size
 
 
+_CHUNK = 1 << 30      # torch's scan-based ops (nonzero, boolean indexing, cumsum) are kept below 2^31 elements per call
+
+
+def _nonzero(mask: torch.Tensor) -> torch.Tensor:
+    if mask.numel() <= _CHUNK:
+        return torch.nonzero(mask).flatten()
+    return torch.cat([torch.nonzero(mask[c: c + _CHUNK]).flatten() + c for c in range(0, mask.numel(), _CHUNK)])
+
+
+def _select(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    if mask.numel() <= _CHUNK:
+        return x[mask]
+    return torch.cat([x[c: c + _CHUNK][mask[c: c + _CHUNK]] for c in range(0, mask.numel(), _CHUNK)])
+
+
+def _cumsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """inclusive prefix sum of x into out (same length; out's dtype accumulates)"""
+    carry = None
+    for c in range(0, x.numel(), _CHUNK):
+        o = out[c: c + _CHUNK]
+        torch.cumsum(x[c: c + _CHUNK], 0, dtype=out.dtype, out=o)
+        if carry is not None:
+            o += carry
+        carry = o[-1].clone()
+    return out
+
+
+def _covered(n: int, beg: torch.Tensor, end: torch.Tensor) -> torch.Tensor:
+    """bool [n]: position lies in at least one of the ranges [beg[k], end[k])"""
+    diff = torch.zeros(n + 1, dtype=torch.int32, device=beg.device)
+    one = torch.ones(beg.numel(), dtype=torch.int32, device=beg.device)
+    diff.index_add_(0, beg, one)
+    diff.index_add_(0, end, -one)
+    return _cumsum(diff[:-1], torch.empty(n, dtype=torch.int32, device=beg.device)) > 0
+
+
 def _arange_like(t: torch.Tensor, n: int) -> torch.Tensor:
     return torch.arange(n, dtype=torch.int64, device=t.device)
 
@@ -35,11 +71,12 @@ def _is_first(eng: Engine, text, ubeg, uend, key_bits: int) -> torch.Tensor:
 def _compact(text: torch.Tensor, total: int, offs: torch.Tensor, keep_byte: torch.Tensor, keep_doc: torch.Tensor):
     """Packed corpus of the kept bytes of the kept documents -> (text', offsets', kept document indices)"""
     csum = torch.zeros(total + 1, dtype=torch.int64, device=text.device)
-    torch.cumsum(keep_byte, 0, out=csum[1:])
+    _cumsum(keep_byte, csum[1:])
     doc_len = csum[offs[1:]] - csum[offs[:-1]]
-    docs = torch.nonzero(keep_doc).flatten()
-    doc_keep_byte = keep_byte & torch.repeat_interleave(keep_doc, offs[1:] - offs[:-1], output_size=total)
-    body = text[:total][doc_keep_byte]
+    del csum
+    docs = _nonzero(keep_doc)
+    keep_byte = keep_byte & _covered(total, offs[:-1][docs], offs[1:][docs])
+    body = _select(text[:total], keep_byte)
     out = torch.zeros(padded_size(body.numel()), dtype=torch.uint8, device=text.device)
     out[: body.numel()] = body
     new_offs = torch.zeros(docs.numel() + 1, dtype=torch.int64, device=text.device)
@@ -85,7 +122,7 @@ def paragraph_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, 
         return torch.zeros(padded_size(0), dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), \
             torch.zeros(0, dtype=torch.int64, device=dev)
     body = text[:total]
-    nl = torch.nonzero(body == 10).flatten()                                  # 0x0A never occurs inside a multi-byte code point
+    nl = _nonzero(body == 10)                                  # 0x0A never occurs inside a multi-byte code point
     doc_of_nl = torch.searchsorted(offs, nl, right=True) - 1
     nl_before = torch.searchsorted(nl, offs[:-1])                             # newlines before each document
     n_units = nd + nl.numel()
@@ -105,23 +142,18 @@ def paragraph_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, 
     doc_of_unit[after_nl] = doc_of_nl
     keep_unit = _is_first(eng, text, ubeg, uend, key_bits)
     # first kept paragraph of every document: it is written without the newline in front of it
-    kept_units = torch.nonzero(keep_unit).flatten()
+    kept_units = _nonzero(keep_unit)
     kd = doc_of_unit[kept_units]
     n_kept = torch.zeros(nd, dtype=torch.int64, device=dev).index_add_(0, kd, torch.ones_like(kd))
     is_first_kept = torch.ones_like(kept_units, dtype=torch.bool)
     if kept_units.numel() > 1:
         is_first_kept[1:] = kd[1:] != kd[:-1]
     start = ubeg[kept_units] - (~is_first_kept).to(torch.int64)               # take the "\n" that precedes the paragraph along
-    diff = torch.zeros(total + 1, dtype=torch.int32, device=dev)
-    one = torch.ones(kept_units.numel(), dtype=torch.int32, device=dev)
-    diff.index_add_(0, start, one)
-    diff.index_add_(0, uend[kept_units], -one)
-    keep_byte = torch.cumsum(diff[:-1], 0) > 0
-    del diff
+    keep_byte = _covered(total, start, uend[kept_units])
     keep_doc = n_kept > 0
     if min_len > 0:
         starts = torch.zeros(total + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(keep_byte & ((body & 0xC0) != 0x80), 0, out=starts[1:])
+        _cumsum(keep_byte & ((body & 0xC0) != 0x80), starts[1:])
         keep_doc &= (starts[offs[1:]] - starts[offs[:-1]]) >= min_len
     return _compact(text, total, offs, keep_byte, keep_doc)
 
@@ -161,12 +193,12 @@ def exact_substr_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tenso
             torch.zeros(0, dtype=torch.int64, device=dev)
     body = text[:total]
     is_start = (body & 0xC0) != 0x80
-    cp_pos = torch.nonzero(is_start).flatten()                                 # byte offset of every code point
+    cp_pos = _nonzero(is_start)                                 # byte offset of every code point
     n_cp = cp_pos.numel()
     cp_end_of_doc = torch.searchsorted(cp_pos, offs[1:])                       # code points before each document's end
     doc_of_cp = torch.searchsorted(offs, cp_pos, right=True) - 1
     g = _arange_like(offs, n_cp)
-    wg = torch.nonzero((g + duplicate_len) < cp_end_of_doc[doc_of_cp]).flatten()
+    wg = _nonzero((g + duplicate_len) < cp_end_of_doc[doc_of_cp])
     del doc_of_cp, g
     gone = torch.zeros(n_cp, dtype=torch.bool, device=dev)
     if wg.numel():
@@ -174,18 +206,16 @@ def exact_substr_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tenso
         uend = cp_pos[wg + duplicate_len]                                      # in range: wg + duplicate_len < the document's last code point + 1
         dup = ~_is_first(eng, text, ubeg, uend, key_bits)
         del ubeg, uend
-        dw = wg[dup]
-        diff = torch.zeros(n_cp + 1, dtype=torch.int32, device=dev)
-        one = torch.ones(dw.numel(), dtype=torch.int32, device=dev)
-        diff.index_add_(0, dw, one)
-        diff.index_add_(0, dw + duplicate_len, -one)
-        gone = torch.cumsum(diff[:-1], 0) > 0                                  # code points covered by a removed window
-        del diff
-    cp_of_byte = torch.cumsum(is_start, 0) - 1
-    keep_byte = ~gone[cp_of_byte] if n_cp else torch.zeros(total, dtype=torch.bool, device=dev)
-    del cp_of_byte
+        dw = _select(wg, dup)
+        gone = _covered(n_cp, dw, dw + duplicate_len)                          # code points covered by a removed window
+    if n_cp:
+        cp_of_byte = _cumsum(is_start, torch.empty(total, dtype=torch.int64, device=dev)) - 1
+        keep_byte = ~gone[cp_of_byte]
+        del cp_of_byte
+    else:
+        keep_byte = torch.zeros(total, dtype=torch.bool, device=dev)
     kept_cp = torch.zeros(n_cp + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(~gone, 0, out=kept_cp[1:])
+    _cumsum(~gone, kept_cp[1:])
     cp_beg_of_doc = torch.searchsorted(cp_pos, offs[:-1])
     keep_doc = (kept_cp[cp_end_of_doc] - kept_cp[cp_beg_of_doc]) >= min_length
     return _compact(text, total, offs, keep_byte, keep_doc)
