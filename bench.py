@@ -374,6 +374,12 @@ def main():
                                  "issue_slot_utilisation = modelled minimum issue time / measured time (DESIGN.md); "
                                  "traffic from profiles/r1_pmc_bench/summary.json"},
         }
+        # HBM-bound stages: SURVEY 8(d)'s algorithmic bytes per document against the 8 TB/s peak
+        hbm_alg = {"band_keys": 4 * K + BANDS * 20, "bucket_edges": 2 * BANDS * 20, "components": BANDS * 8 + 4}
+        res["hbm_stages"] = {k: {"ms": res["stage_ms_per_step_rank0"].get(k), "algorithmic_bytes_per_doc": v,
+                                 "achieved_gb_per_s": v * n_local / (res["stage_ms_per_step_rank0"][k] * 1e6),
+                                 "frac_of_8TBps": v * n_local / (res["stage_ms_per_step_rank0"][k] * 1e6) / 8000.0}
+                             for k, v in hbm_alg.items() if res["stage_ms_per_step_rank0"].get(k)}
         if cpu is not None:
             res["cpu_baseline"] = cpu
         if args.stages and world == 1:

@@ -125,8 +125,8 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
  *   tuple(i) = tuple_base + (i / rec_per_doc)*doc_stride + (i % rec_per_doc)*band_stride
  *   SIG layout:    tuple_base = sig, rec_per_doc = bands, doc_stride = K, band_stride = rows
  *   PACKED layout: tuple_base = tuples, rec_per_doc = 1, doc_stride = rows, band_stride = 0
- * Workspace (caller-allocated): tab_key u64[tab_size], tab_rep u32[tab_size]; tab_size a
- * power of two >= 2*n_rec.  The call clears it.
+ * Workspace (caller-allocated): table u64[tab_size], tab_size a power of two >= 2*n_rec.
+ * The call clears it.
  * Output: for every record that is not the representative (lowest record index) of its
  * bucket one edge (doc, doc_of_representative), appended to edge_u/edge_v (u32 global doc
  * indices; order of edges unspecified, set deterministic).  *n_edges (device u64) counts
@@ -138,7 +138,7 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
  * record index of the representative of the record's surrogate slot (bucket id for tests). */
 int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, uint64_t n_rec,
                      const uint32_t* tuple_base, uint64_t rec_per_doc, uint64_t doc_stride,
-                     uint64_t band_stride, int rows, uint64_t* tab_key, uint32_t* tab_rep,
+                     uint64_t band_stride, int rows, uint64_t* table,
                      uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap,
                      uint64_t* n_edges, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll,
                      uint64_t* rec_bucket);

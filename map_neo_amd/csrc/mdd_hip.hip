@@ -683,16 +683,24 @@ struct TupleAddr {
     }
 };
 
-__global__ void __launch_bounds__(256) bucket_insert_kernel(const uint64_t* key, uint64_t n_rec, unsigned long long* tab_key,
-                                                            uint32_t* tab_rep, uint64_t tab_mask) {
+// One 8-byte table entry = (high half of the surrogate key << 32 | lowest record index seen): a single random
+// atomic per record (the claim) -- every device atomic is a whole memory transaction, so this halves the
+// stage's traffic against a key array + a representative array.  A same-tag entry of another key is just one
+// more surrogate collision: the tuple comparison in bucket_link_kernel catches it.
+constexpr unsigned long long TAB_EMPTY = ~0ULL;
+
+__global__ void __launch_bounds__(256) bucket_insert_kernel(const uint64_t* key, uint64_t n_rec, unsigned long long* tab,
+                                                            uint64_t tab_mask) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
     unsigned long long k = key[i];
+    unsigned long long val = (k & 0xFFFFFFFF00000000ULL) | (uint32_t)i;
     uint64_t slot = mix64(k) & tab_mask;
     for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: table is never full (size >= 2*n_rec)
-        unsigned long long cur = atomicCAS(&tab_key[slot], 0ULL, k);
-        if (cur == 0ULL || cur == k) {
-            atomicMin(&tab_rep[slot], (uint32_t)i);
+        unsigned long long cur = atomicCAS(&tab[slot], TAB_EMPTY, val);
+        if (cur == TAB_EMPTY) return;
+        if ((cur >> 32) == (val >> 32)) {
+            if (cur > val) atomicMin(&tab[slot], val);
             return;
         }
         slot = (slot + 1) & tab_mask;
@@ -720,8 +728,7 @@ __device__ __forceinline__ void append_edge(uint32_t u, uint32_t v, bool have, u
 }
 
 __global__ void __launch_bounds__(256) bucket_link_kernel(const uint64_t* key, const uint64_t* meta, uint64_t n_rec, TupleAddr ta,
-                                                          const unsigned long long* tab_key, const uint32_t* tab_rep,
-                                                          uint64_t tab_mask, uint32_t* edge_u, uint32_t* edge_v,
+                                                          const unsigned long long* tab, uint64_t tab_mask, uint32_t* edge_u, uint32_t* edge_v,
                                                           uint64_t edge_cap, unsigned long long* n_edges, uint64_t* coll_idx,
                                                           uint64_t coll_cap, unsigned long long* n_coll, uint64_t* rec_bucket) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -732,12 +739,12 @@ __global__ void __launch_bounds__(256) bucket_link_kernel(const uint64_t* key, c
         uint64_t slot = mix64(k) & tab_mask;
         uint32_t rep = (uint32_t)i;
         for (uint64_t probe = 0; probe <= tab_mask; probe++) {
-            unsigned long long cur = tab_key[slot];
-            if (cur == k) {
-                rep = tab_rep[slot];
+            unsigned long long cur = tab[slot];
+            if (cur == TAB_EMPTY) break;  // cannot happen after insert; defensive
+            if ((cur >> 32) == (k >> 32)) {
+                rep = (uint32_t)cur;
                 break;
             }
-            if (cur == 0ULL) break;  // cannot happen after insert; defensive
             slot = (slot + 1) & tab_mask;
         }
         if (rec_bucket) rec_bucket[i] = rep;
@@ -1078,9 +1085,9 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
 }
 
 int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, uint64_t n_rec, const uint32_t* tuple_base,
-                     uint64_t rec_per_doc, uint64_t doc_stride, uint64_t band_stride, int rows, uint64_t* tab_key,
-                     uint32_t* tab_rep, uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap,
-                     uint64_t* n_edges, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll, uint64_t* rec_bucket) {
+                     uint64_t rec_per_doc, uint64_t doc_stride, uint64_t band_stride, int rows, uint64_t* table,
+                     uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap, uint64_t* n_edges,
+                     uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll, uint64_t* rec_bucket) {
     REQUIRE(ctx && n_edges && n_coll, "mdd_bucket_edges: NULL counter");
     REQUIRE(n_rec <= 0xFFFFFFFEull, "mdd_bucket_edges: n_rec=%llu exceeds 2^32-2", (unsigned long long)n_rec);
     REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_rec,
@@ -1090,18 +1097,17 @@ int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, ui
     HIP_TRY(hipMemsetAsync(n_edges, 0, sizeof(uint64_t), ctx->stream));
     HIP_TRY(hipMemsetAsync(n_coll, 0, sizeof(uint64_t), ctx->stream));
     if (n_rec == 0) return MDD_OK;
-    REQUIRE(key && meta && tuple_base && tab_key && tab_rep && (edge_cap == 0 || (edge_u && edge_v)) &&
+    REQUIRE(key && meta && tuple_base && table && (edge_cap == 0 || (edge_u && edge_v)) &&
                 (coll_cap == 0 || coll_idx),
             "mdd_bucket_edges: NULL buffer");
-    HIP_TRY(hipMemsetAsync(tab_key, 0, sizeof(uint64_t) * tab_size, ctx->stream));
-    HIP_TRY(hipMemsetAsync(tab_rep, 0xFF, sizeof(uint32_t) * tab_size, ctx->stream));
+    HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
     unsigned g = grid_for(n_rec, 256);
     hipLaunchKernelGGL(bucket_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key, n_rec,
-                       reinterpret_cast<unsigned long long*>(tab_key), tab_rep, tab_size - 1);
+                       reinterpret_cast<unsigned long long*>(table), tab_size - 1);
     HIP_TRY(hipGetLastError());
     TupleAddr ta{tuple_base, rec_per_doc, doc_stride, band_stride, rows};
     hipLaunchKernelGGL(bucket_link_kernel, dim3(g), dim3(256), 0, ctx->stream, key, meta, n_rec, ta,
-                       reinterpret_cast<const unsigned long long*>(tab_key), tab_rep, tab_size - 1, edge_u, edge_v, edge_cap,
+                       reinterpret_cast<const unsigned long long*>(table), tab_size - 1, edge_u, edge_v, edge_cap,
                        reinterpret_cast<unsigned long long*>(n_edges), coll_idx, coll_cap,
                        reinterpret_cast<unsigned long long*>(n_coll), rec_bucket);
     HIP_TRY(hipGetLastError());

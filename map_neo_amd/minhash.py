@@ -195,8 +195,7 @@ class Engine:
         tab_size = 2
         while tab_size < 2 * max(1, n_rec):
             tab_size *= 2
-        tab_key = self.empty(tab_size, torch.int64)
-        tab_rep = self.empty(tab_size, torch.int32)
+        table = self.empty(tab_size, torch.int64)
         eu = self.empty(max(1, n_rec), torch.int32)
         ev = self.empty(max(1, n_rec), torch.int32)
         coll_cap = max(1024, n_rec)
@@ -204,7 +203,7 @@ class Engine:
         cnt = torch.zeros(2, dtype=torch.int64, device=self.device)
         rb = self.empty(n_rec, torch.int64) if want_buckets else None
         _lib.check(self.L.mdd_bucket_edges(self.ctx, _ptr(key), _ptr(meta), n_rec, _ptr(tuple_base), rec_per_doc,
-                                           doc_stride, band_stride, rows, _ptr(tab_key), _ptr(tab_rep), tab_size,
+                                           doc_stride, band_stride, rows, _ptr(table), tab_size,
                                            _ptr(eu), _ptr(ev), n_rec, C.c_void_p(cnt.data_ptr()), _ptr(coll), coll_cap,
                                            C.c_void_p(cnt.data_ptr() + 8), _ptr(rb)), "mdd_bucket_edges")
         n_edges, n_coll = (int(x) for x in cnt.cpu().tolist())
