@@ -174,7 +174,7 @@ int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint6
  * row_number over (id, pos)) and Exact_Substring_Deduplication/exact_substr_dedup.py:23-24,
  * 44-47,83 (_get_hash + groupByKey + dup_list[1:]) -- all under
  * Matrix/english_data_clean_pipeline/dedup/.  Unit u = bytes [ubeg[u], uend[u]) of `text`
- * (8-byte aligned, MDD_TEXT_PAD spare bytes); units may overlap.
+ * (8-byte aligned, text_bytes long + MDD_TEXT_PAD spare bytes; ranges are clamped to it); units may overlap.
  *   first_of[u] = smallest unit index whose bytes are identical to unit u's (u itself if none).
  * Equal SHA-256 <=> equal bytes, so these are the reference's groups with "first" = lowest index.
  * A 64-bit content hash (truncated to key_bits; pass 64) only picks the table slot; units whose
@@ -182,7 +182,7 @@ int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint6
  * coll_idx / *n_coll (device u64) for exact resolution by the caller.
  * Workspaces: key_scratch u64[n_units]; table u64[tab_size], tab_size a power of two
  * >= 2*n_units.  avg_unit_bytes picks thread-per-unit (< 256) or wave-per-unit hashing. */
-int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
+int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
                     uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
                     uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
 
@@ -194,11 +194,11 @@ int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, con
  *          (then out_len[d] = 0 and the caller normalises that document with the Python steps);
  *   write: normalised bytes of every document with non_ascii[d] == 0 to
  *          out_text[out_offsets[d] .. out_offsets[d] + out_len[d]).
- * All pointers are device memory. */
-int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs, uint64_t* out_len,
-                           uint8_t* non_ascii);
-int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs,
-                           const uint8_t* non_ascii, const uint64_t* out_offsets, uint8_t* out_text);
+ * All pointers are device memory; out_text holds out_capacity bytes (nothing is written beyond). */
+int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                           uint64_t* out_len, uint8_t* non_ascii);
+int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                           const uint8_t* non_ascii, const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity);
 
 /* Measurement helper: runs `iters` iterations of a dependency-free
  * v_xor/v_add/v_lshr mix on every CU and reports the measured int32 VALU lane-op rate in

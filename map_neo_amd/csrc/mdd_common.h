@@ -37,6 +37,16 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ uint32_t below(uint64_t m) {  // set bits of m in lanes below this one
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// Document d = [beg, end) of the text.  offsets live in device memory and cannot be validated on the host
+// without a synchronisation, so every kernel clamps them instead: end <= text_bytes, beg <= end.  Malformed
+// offsets then give meaningless signatures but never an access outside the caller's allocation.
+__device__ __forceinline__ void doc_range(const uint64_t* offsets, uint64_t d, uint64_t text_bytes, uint64_t& beg, uint64_t& end) {
+    beg = offsets[d];
+    end = offsets[d + 1];
+    end = end < text_bytes ? end : text_bytes;
+    beg = beg < end ? beg : end;
+}
+
 inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 }  // namespace mddi
 

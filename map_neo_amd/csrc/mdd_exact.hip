@@ -18,6 +18,17 @@ using namespace mddi;
 
 constexpr uint64_t C1 = 0x9E3779B97F4A7C15ULL, C2 = 0xD6E8FEB86659FD93ULL;
 
+// Unit u = [b, b + len) of the text, clamped into [0, text_bytes]: ranges come from device memory and cannot be
+// validated on the host without a synchronisation; malformed ones must not reach outside the allocation.
+__device__ __forceinline__ void unit_range(const uint64_t* ubeg, const uint64_t* uend, uint64_t u, uint64_t text_bytes, uint64_t& b,
+                                           uint64_t& len) {
+    uint64_t e = uend[u];
+    b = ubeg[u];
+    e = e < text_bytes ? e : text_bytes;
+    b = b < e ? b : e;
+    len = e - b;
+}
+
 // 8 bytes at absolute byte address a (any alignment) from an 8-byte aligned base; the allocation
 // extends MDD_TEXT_PAD bytes past the text, so the second load is always in bounds
 __device__ __forceinline__ uint64_t load8(const uint64_t* t64, uint64_t a) {
@@ -42,22 +53,26 @@ __device__ __forceinline__ uint64_t finish_key(uint64_t sum, uint64_t len, int k
     return h ? h : 1ULL;
 }
 
-__global__ void __launch_bounds__(256) exact_hash_thread_kernel(const uint64_t* t64, const uint64_t* ubeg, const uint64_t* uend,
-                                                                uint64_t n, int key_bits, uint64_t* key) {
+__global__ void __launch_bounds__(256) exact_hash_thread_kernel(const uint64_t* t64, uint64_t text_bytes, const uint64_t* ubeg,
+                                                                const uint64_t* uend, uint64_t n, int key_bits, uint64_t* key) {
     uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n) return;
-    uint64_t b = ubeg[u], len = uend[u] - b, nch = (len + 7) >> 3, sum = 0;
+    uint64_t b, len;
+    unit_range(ubeg, uend, u, text_bytes, b, len);
+    uint64_t nch = (len + 7) >> 3, sum = 0;
     for (uint64_t c = 0; c < nch; c++) sum += chunk_term(t64, b, len, c);
     key[u] = finish_key(sum, len, key_bits);
 }
 
 // one wave per unit: for long units (documents)
-__global__ void __launch_bounds__(256) exact_hash_wave_kernel(const uint64_t* t64, const uint64_t* ubeg, const uint64_t* uend,
-                                                              uint64_t n, int key_bits, uint64_t* key) {
+__global__ void __launch_bounds__(256) exact_hash_wave_kernel(const uint64_t* t64, uint64_t text_bytes, const uint64_t* ubeg,
+                                                              const uint64_t* uend, uint64_t n, int key_bits, uint64_t* key) {
     uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (u >= n) return;
     uint32_t lane = lane_id();
-    uint64_t b = ubeg[u], len = uend[u] - b, nch = (len + 7) >> 3, sum = 0;
+    uint64_t b, len;
+    unit_range(ubeg, uend, u, text_bytes, b, len);
+    uint64_t nch = (len + 7) >> 3, sum = 0;
     for (uint64_t c = lane; c < nch; c += 64) sum += chunk_term(t64, b, len, c);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -91,8 +106,8 @@ __global__ void __launch_bounds__(256) exact_insert_kernel(const uint64_t* key, 
     }
 }
 
-__global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, const uint64_t* ubeg, const uint64_t* uend,
-                                                         const uint64_t* key, uint64_t n, const unsigned long long* tab,
+__global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, uint64_t text_bytes, const uint64_t* ubeg,
+                                                         const uint64_t* uend, const uint64_t* key, uint64_t n, const unsigned long long* tab,
                                                          uint64_t tab_mask, uint32_t* first_of, uint64_t* coll_idx,
                                                          uint64_t coll_cap, unsigned long long* n_coll) {
     uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,7 +126,9 @@ __global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, co
     }
     uint32_t out = (uint32_t)u;
     if (rep != (uint32_t)u) {
-        uint64_t b = ubeg[u], len = uend[u] - b, rb = ubeg[rep], rlen = uend[rep] - rb;
+        uint64_t b, len, rb, rlen;
+        unit_range(ubeg, uend, u, text_bytes, b, len);
+        unit_range(ubeg, uend, rep, text_bytes, rb, rlen);
         bool same = len == rlen;
         uint64_t nch = (len + 7) >> 3;
         for (uint64_t c = 0; same && c < nch; c++) {
@@ -135,7 +152,7 @@ __global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, co
 
 }  // namespace
 
-extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
+extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
                                uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
                                uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll) {
     REQUIRE(ctx && n_coll, "mdd_exact_group: NULL argument");
@@ -151,11 +168,11 @@ extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t
     const uint64_t* t64 = reinterpret_cast<const uint64_t*>(text);
     if (avg_unit_bytes >= 256) {
         REQUIRE(n_units * 64 / 256 + 1 < 0x7FFFFFFFull, "mdd_exact_group: too many units for one launch");
-        hipLaunchKernelGGL(exact_hash_wave_kernel, dim3(grid_for(n_units * 64, 256)), dim3(256), 0, ctx->stream, t64, ubeg, uend,
-                           n_units, key_bits, key_scratch);
+        hipLaunchKernelGGL(exact_hash_wave_kernel, dim3(grid_for(n_units * 64, 256)), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg,
+                           uend, n_units, key_bits, key_scratch);
     } else {
-        hipLaunchKernelGGL(exact_hash_thread_kernel, dim3(grid_for(n_units, 256)), dim3(256), 0, ctx->stream, t64, ubeg, uend,
-                           n_units, key_bits, key_scratch);
+        hipLaunchKernelGGL(exact_hash_thread_kernel, dim3(grid_for(n_units, 256)), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg,
+                           uend, n_units, key_bits, key_scratch);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
@@ -163,7 +180,7 @@ extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, const uint64_t
     hipLaunchKernelGGL(exact_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key_scratch, n_units,
                        reinterpret_cast<unsigned long long*>(table), tab_size - 1);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(exact_link_kernel, dim3(g), dim3(256), 0, ctx->stream, t64, ubeg, uend, key_scratch, n_units,
+    hipLaunchKernelGGL(exact_link_kernel, dim3(g), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg, uend, key_scratch, n_units,
                        reinterpret_cast<const unsigned long long*>(table), tab_size - 1, first_of, coll_idx, coll_cap,
                        reinterpret_cast<unsigned long long*>(n_coll));
     HIP_TRY(hipGetLastError());

@@ -335,8 +335,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             beg = A.doc_begin;
             end = A.doc_end;
         } else {
-            beg = A.offsets[d];
-            end = A.offsets[d + 1];
+            doc_range(A.offsets, d, A.text_bytes, beg, end);
         }
         const uint32_t len = (uint32_t)(end - beg);
         const uint32_t seg_len = DUMP ? 0xFFFFFFFFu : A.seg_bytes;
@@ -382,6 +381,24 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 uint32_t j_end = len - width + 1 < seg_end ? len - width + 1 : seg_end;
                 ascii_total = j_end > seg_beg ? j_end - seg_beg : 0;
             }
+            // boundary scan input: the scan window is 256 bytes, lane l owns the 4 bytes at pos + 4l, i.e. one
+            // unaligned dword = two coalesced aligned loads.  The next TWO windows are kept in flight in
+            // registers (a round of 64 word shingles consumes ~1.3 windows), so their latency hides behind the
+            // SHA-1 + permute work of the current round instead of stalling the ring fill.
+            uint32_t pfa_lo = 0, pfa_hi = 0, pfb_lo = 0, pfb_hi = 0;
+            auto window_load = [&](uint32_t wpos, uint32_t& lo, uint32_t& hi) {
+                uint32_t p0 = wpos + 4u * lane;
+                bool in = wpos < len && p0 < len;  // reads stay within 8 bytes of the document's end
+                uint32_t i = (boff + p0) >> 2;
+                lo = in ? tv.docw[i] : 0u;
+                hi = in ? tv.docw[i + 1] : 0u;
+            };
+            bool carry_sp = true;  // word unit: the byte before the scan window is a space (or the document starts)
+            if (!ascii) {
+                window_load(pos, pfa_lo, pfa_hi);
+                window_load(pos + 256u, pfb_lo, pfb_hi);
+                if (unit != MDD_UNIT_CHAR && pos > 0 && pos <= len) carry_sp = text[beg + pos - 1] == 0x20;
+            }
 
             for (;;) {
                 uint32_t nvalid;
@@ -401,21 +418,31 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         if (scan_done || n_ent - n_done >= 64u + look) break;
                         // window = doc-relative bytes [pos, pos+256); lane handles 4 of them
                         uint32_t p0 = pos + 4u * lane;
+                        uint32_t w4 = __builtin_amdgcn_alignbyte(pfa_hi, pfa_lo, boff);  // bytes p0 .. p0+3
+                        uint32_t nb = (pfa_hi >> (8u * boff)) & 0xFFu;                     // byte p0+4
+                        pfa_lo = pfb_lo;
+                        pfa_hi = pfb_hi;
+                        window_load(pos + 512u, pfb_lo, pfb_hi);
+                        uint32_t nval = p0 < len ? (len - p0 < 4u ? len - p0 : 4u) : 0u;
                         uint32_t fs = 0, fe = 0;
                         if (unit == MDD_UNIT_CHAR) {
 #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                uint32_t p = p0 + k;
-                                if (p < len && (text[beg + p] & 0xC0u) != 0x80u) fs |= 1u << k;
-                            }
+                            for (int k = 0; k < 4; k++)
+                                if ((uint32_t)k < nval && ((w4 >> (8 * k)) & 0xC0u) != 0x80u) fs |= 1u << k;
                         } else {
-                            bool prev_sp = (p0 == 0 || p0 > len) ? true : text[beg + p0 - 1] == 0x20;
+                            bool spk[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) spk[k] = (uint32_t)k < nval ? ((w4 >> (8 * k)) & 0xFFu) == 0x20u : true;
+                            bool next4 = p0 + 4u < len ? nb == 0x20u : true;
+                            uint32_t last = spk[3] ? 1u : 0u;
+                            uint32_t up = (uint32_t)__shfl_up((int)last, 1, 64);
+                            bool prev_sp = lane == 0 ? carry_sp : up != 0u;
+                            carry_sp = __builtin_amdgcn_readlane(last, 63) != 0u;
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
-                                uint32_t p = p0 + k;
-                                bool in = p < len;
-                                bool sp = in ? text[beg + p] == 0x20 : true;
-                                bool next_sp = (p + 1 < len) ? text[beg + p + 1] == 0x20 : true;
+                                bool in = (uint32_t)k < nval;
+                                bool sp = spk[k];
+                                bool next_sp = k < 3 ? spk[k + 1] : next4;
                                 if (in && !sp && prev_sp) fs |= 1u << k;
                                 if (in && !sp && next_sp) fe |= 1u << k;
                                 prev_sp = sp;
@@ -591,11 +618,14 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 
 // One thread per document: documents longer than seg_bytes get their extra segments queued
 // and their signature row preset to 0xFFFFFFFF (their segments combine with atomicMin).
-__global__ void __launch_bounds__(256) seg_plan_kernel(const uint64_t* offsets, uint64_t n_docs, uint32_t seg_bytes, uint64_t* items,
-                                                       unsigned long long* n_items, uint64_t max_items, uint32_t* sig, int K) {
+__global__ void __launch_bounds__(256) seg_plan_kernel(const uint64_t* offsets, uint64_t n_docs, uint64_t text_bytes, uint32_t seg_bytes,
+                                                       uint64_t* items, unsigned long long* n_items, uint64_t max_items, uint32_t* sig,
+                                                       int K) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_docs) return;
-    uint64_t len = offsets[d + 1] - offsets[d];
+    uint64_t beg, end;
+    doc_range(offsets, d, text_bytes, beg, end);
+    uint64_t len = end - beg;
     if (len <= seg_bytes) return;
     uint64_t nseg = (len + seg_bytes - 1) / seg_bytes;
     unsigned long long base = atomicAdd(n_items, (unsigned long long)(nseg - 1));
@@ -993,8 +1023,8 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
     A.max_items = max_items;
     A.work_counter = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 1);
     HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));
-    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, A.seg_bytes,
-                       ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, sig_out, K);
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes,
+                       A.seg_bytes, ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, sig_out, K);
     HIP_TRY(hipGetLastError());
     // persistent grid: enough waves to fill every SIMD several times over; surplus waves find the
     // counter exhausted and leave at once

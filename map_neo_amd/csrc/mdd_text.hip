@@ -23,15 +23,17 @@ __device__ __forceinline__ bool is_punct(uint32_t c) {
 __device__ __forceinline__ bool is_space(uint32_t c) { return (c - 9u <= 4u) | (c - 28u <= 4u); }
 
 template <bool WRITE>
-__global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ offs, uint64_t n,
-                                                      uint64_t* out_len, uint8_t* non_ascii,
-                                                      const uint64_t* __restrict__ out_offs, uint8_t* __restrict__ out_text) {
+__global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                      const uint64_t* __restrict__ offs, uint64_t n, uint64_t* out_len,
+                                                      uint8_t* non_ascii, const uint64_t* __restrict__ out_offs,
+                                                      uint8_t* __restrict__ out_text, uint64_t out_cap) {
     const uint32_t lane = lane_id();
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;  // lanes below this one
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
     for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
         if (WRITE && non_ascii[d]) continue;
-        const uint64_t b = offs[d], e = offs[d + 1];
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
         const uint64_t o = WRITE ? out_offs[d] : 0;
         uint64_t cnt = 0;
         bool prev_ws = false, seen = false, bad = false;  // wave-uniform carries between 64-byte steps
@@ -60,8 +62,9 @@ __global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict_
                 const uint64_t S = __ballot(sp);
                 if (WRITE && is_n) {
                     uint64_t pos = o + cnt + __builtin_popcountll(N & lt) + __builtin_popcountll(S & lt);
-                    if (sp) out_text[pos++] = ' ';
-                    out_text[pos] = (uint8_t)((c - 65u <= 25u) ? c + 32u : c);
+                    if (sp && pos < out_cap) out_text[pos] = ' ';
+                    pos += sp;
+                    if (pos < out_cap) out_text[pos] = (uint8_t)((c - 65u <= 25u) ? c + 32u : c);  // out_offsets are the caller's: stay inside out_text
                 }
                 cnt += __builtin_popcountll(N) + __builtin_popcountll(S);
                 if (K) prev_ws = (W >> (63 - __builtin_clzll(K))) & 1;
@@ -82,26 +85,26 @@ unsigned norm_grid(const mdd_ctx* ctx, uint64_t n) {
 
 }  // namespace
 
-extern "C" int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs, uint64_t* out_len,
-                                      uint8_t* non_ascii) {
+extern "C" int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                                      uint64_t* out_len, uint8_t* non_ascii) {
     REQUIRE(ctx, "mdd_normalize_en_count: NULL context");
     if (n_docs == 0) return MDD_OK;
     REQUIRE(text && offsets && out_len && non_ascii, "mdd_normalize_en_count: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(norm_en_kernel<false>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, offsets, n_docs, out_len,
-                       non_ascii, (const uint64_t*)nullptr, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(norm_en_kernel<false>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
+                       out_len, non_ascii, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
 
-extern "C" int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs,
-                                      const uint8_t* non_ascii, const uint64_t* out_offsets, uint8_t* out_text) {
+extern "C" int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                                      const uint8_t* non_ascii, const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity) {
     REQUIRE(ctx, "mdd_normalize_en_write: NULL context");
     if (n_docs == 0) return MDD_OK;
     REQUIRE(text && offsets && non_ascii && out_offsets && out_text, "mdd_normalize_en_write: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(norm_en_kernel<true>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, offsets, n_docs,
-                       (uint64_t*)nullptr, const_cast<uint8_t*>(non_ascii), out_offsets, out_text);
+    hipLaunchKernelGGL(norm_en_kernel<true>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
+                       (uint64_t*)nullptr, const_cast<uint8_t*>(non_ascii), out_offsets, out_text, out_capacity);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

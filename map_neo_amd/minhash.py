@@ -256,7 +256,7 @@ class Engine:
         table = self.empty(tab_size, torch.int64)
         coll = self.empty(max(1024, n), torch.int64)
         cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
-        _lib.check(self.L.mdd_exact_group(self.ctx, _ptr(text), _ptr(ubeg), _ptr(uend), n, total // n, key_bits, _ptr(key),
+        _lib.check(self.L.mdd_exact_group(self.ctx, _ptr(text), max(0, text.numel() - TEXT_PAD), _ptr(ubeg), _ptr(uend), n, total // n, key_bits, _ptr(key),
                                           _ptr(table), tab_size, _ptr(first_of), _ptr(coll), coll.numel(), _ptr(cnt)),
                    "mdd_exact_group")
         n_coll = int(cnt.item())
@@ -281,14 +281,15 @@ class Engine:
         n = offsets.numel() - 1
         out_len = torch.zeros(max(n, 0), dtype=torch.int64, device=self.device)
         flags = torch.zeros(max(n, 0), dtype=torch.uint8, device=self.device)
-        _lib.check(self.L.mdd_normalize_en_count(self.ctx, _ptr(text), _ptr(offsets), n, _ptr(out_len), _ptr(flags)),
+        text_bytes = max(0, text.numel() - TEXT_PAD)
+        _lib.check(self.L.mdd_normalize_en_count(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(out_len), _ptr(flags)),
                    "mdd_normalize_en_count")
         out_offs = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
         torch.cumsum(out_len, 0, out=out_offs[1:])
         total = int(out_offs[-1].item()) if n > 0 else 0
         out_text = torch.zeros(padded_size(total), dtype=torch.uint8, device=self.device)
-        _lib.check(self.L.mdd_normalize_en_write(self.ctx, _ptr(text), _ptr(offsets), n, _ptr(flags), _ptr(out_offs),
-                                                 _ptr(out_text)), "mdd_normalize_en_write")
+        _lib.check(self.L.mdd_normalize_en_write(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(flags), _ptr(out_offs),
+                                                 _ptr(out_text), total), "mdd_normalize_en_write")
         return out_text, out_offs, flags
 
     def valu_calibrate(self, iters: int = 20000) -> float:
