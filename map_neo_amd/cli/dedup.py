@@ -17,6 +17,8 @@ ZH-1:52-54).  --normalize en applies EN:31-40 before hashing (the EN pipeline), 
 the raw field (the ZH pipeline).  The survivor of a cluster is its smallest id when ids come
 from the data (EN:145) and its first document in input order otherwise.
 LSH parameters default to the reference's constants (EN:17-20 / ZH-1:14-17).
+Multi-GPU: `torchrun --nproc-per-node N -m map_neo_amd.cli.dedup ...` -- one process per GPU, each ingests a
+contiguous block of the shards; same outputs.
 """
 from __future__ import annotations
 
@@ -39,6 +41,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--content_field", default="raw_content")
     p.add_argument("--normalize", choices=["en", "none"], default="en")
     p.add_argument("--write_shards", action="store_true")
+    p.add_argument("--distributed", action="store_true",
+                   help="use the multi-GPU path even with one rank (implied by WORLD_SIZE > 1 under torchrun)")
     p.add_argument("--width", type=int, default=13)
     p.add_argument("--ngram_unit", choices=["char", "word"], default="char")
     p.add_argument("--num_perm", type=int, default=128)
@@ -100,20 +104,48 @@ def _write_shard(task):
     return kept
 
 
-def run(args) -> dict:
+def run(args, engine_factory=None) -> dict:
+    """Single process: one GPU.  Under torchrun (WORLD_SIZE > 1, or --distributed): one process per GPU, every rank
+    ingests a contiguous block of the shards, band records are exchanged by all-to-all, the union-find is
+    replicated (map_neo_amd.dedup.cluster_distributed), every rank writes the outputs of its own shards and rank 0
+    stitches the id / cluster lists together.  `engine_factory(device)` lets tests inject a CPU backend."""
     from .. import hostio
-    files = hostio.list_files(args.input_dir)
-    os.makedirs(args.output_dir, exist_ok=True)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or getattr(args, "distributed", False)
+    all_files = hostio.list_files(args.input_dir)
+    lo, hi = (len(all_files) * rank) // world, (len(all_files) * (rank + 1)) // world
+    files = all_files[lo:hi]
+    if rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.time()
-    pool = mp.get_context("fork").Pool(max(1, args.workers))      # forked before this process touches the GPU
+    pool = mp.get_context("fork").Pool(max(1, args.workers // world))      # forked before this process touches the GPU
     try:
         parsed = pool.imap(_parse_shard, [(p, args.id_field, args.content_field, args.normalize) for p in files])
         import torch
 
-        from ..dedup import cluster_local
-        from ..minhash import Engine, as_u32, padded_size
-        eng = Engine(args.device)
+        from ..dedup import cluster_distributed, cluster_local
+        from ..minhash import as_u32, padded_size
+        if engine_factory is not None:
+            eng = engine_factory(local_rank)
+        else:
+            from ..minhash import Engine
+            eng = Engine(local_rank if distributed else args.device)
+        dist = None
+        if distributed:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+                if eng.device.type == "cuda":
+                    dist.init_process_group("nccl", device_id=eng.device)
+                else:
+                    dist.init_process_group("gloo")
         sigs, all_ids, cand_ids, any_synth = [], [], [], False
+
         def padded(text):
             buf = np.zeros(padded_size(text.size), dtype=np.uint8)
             buf[: text.size] = text
@@ -140,23 +172,41 @@ def run(args) -> dict:
         t1 = time.time()
         n = len(cand_ids)
         sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
-        out = cluster_local(eng, sig, args.bands, args.rows)
-        labels = as_u32(out["labels"])
-        members = np.flatnonzero(labels != np.arange(n, dtype=np.uint32))
-        clustered = sorted(set(members.tolist()) | set(labels[members].tolist()))
+        if not distributed:
+            doc_base, n_global = 0, n
+            labels = as_u32(cluster_local(eng, sig, args.bands, args.rows)["labels"])
+        else:
+            counts = [None] * world
+            dist.all_gather_object(counts, (n, any_synth))
+            doc_base, n_global = sum(c for c, _ in counts[:rank]), sum(c for c, _ in counts)
+            any_synth = any(s for _, s in counts)
+            labels = as_u32(cluster_distributed(eng, sig, doc_base, n_global, args.bands, args.rows)["labels"])
+        # documents of clusters with more than one member (global indices), and this rank's share of them
+        gidx = np.arange(n_global, dtype=np.uint32)
+        in_cluster = labels != gidx
+        in_cluster[labels[in_cluster]] = True
+        mine = np.flatnonzero(in_cluster[doc_base: doc_base + n])
+        pairs = [(int(labels[doc_base + k]), cand_ids[k], doc_base + int(k)) for k in mine.tolist()]
+        if distributed:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, pairs)
+            all_pairs = [p for part in gathered for p in part]
+        else:
+            all_pairs = pairs
         # representative: smallest id (EN:145) unless ids were synthesised, then first in input order
         rep = {}
-        for k in clustered:
-            l = int(labels[k])
-            if l not in rep or (not any_synth and cand_ids[k] < rep[l]):
-                rep[l] = cand_ids[k]
-        remove_ids = {cand_ids[k] for k in clustered if cand_ids[k] != rep[int(labels[k])]}
+        for l, d, g in all_pairs:
+            if l not in rep or ((g, d) if any_synth else (d, g)) < rep[l][0]:
+                rep[l] = ((g, d) if any_synth else (d, g), d)
+        rep = {l: v[1] for l, v in rep.items()}
+        remove_ids = {d for l, d, _ in all_pairs if d != rep[l]}
         t2 = time.time()
-        with open(os.path.join(args.output_dir, "clusters.jsonl"), "w", encoding="utf8") as f:
-            for k in clustered:
-                f.write(json.dumps({"doc_id": cand_ids[k], "cluster": rep[int(labels[k])]}, ensure_ascii=False) + "\n")
-        with open(os.path.join(args.output_dir, "removed_ids.txt"), "w", encoding="utf8") as fr, \
-                open(os.path.join(args.output_dir, "kept_ids.txt"), "w", encoding="utf8") as fk:
+        suffix = ".part%05d" % rank if distributed else ""
+        with open(os.path.join(args.output_dir, "clusters.jsonl" + suffix), "w", encoding="utf8") as f:
+            for l, d, _ in pairs:
+                f.write(json.dumps({"doc_id": d, "cluster": rep[l]}, ensure_ascii=False) + "\n")
+        with open(os.path.join(args.output_dir, "removed_ids.txt" + suffix), "w", encoding="utf8") as fr, \
+                open(os.path.join(args.output_dir, "kept_ids.txt" + suffix), "w", encoding="utf8") as fk:
             for d in all_ids:
                 (fr if d in remove_ids else fk).write(f"{d}\n")
         kept_rows = None
@@ -170,11 +220,26 @@ def run(args) -> dict:
         pool.close()
         pool.join()
     summary = {"n_rows": len(all_ids), "n_hashed": n, "n_removed_ids": len(remove_ids),
-               "n_clusters": len(rep), "n_clustered_docs": len(clustered), "kept_rows_written": kept_rows,
-               "t_parse_signatures_s": t1 - t0, "t_cluster_s": t2 - t1, "t_write_s": t3 - t2}
-    with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
-        json.dump(summary, f)
-    print(json.dumps(summary), file=sys.stderr)
+               "n_clusters": len(rep), "n_clustered_docs": len(all_pairs), "kept_rows_written": kept_rows,
+               "t_parse_signatures_s": t1 - t0, "t_cluster_s": t2 - t1, "t_write_s": t3 - t2, "world": world}
+    if distributed:
+        parts = [None] * world
+        dist.all_gather_object(parts, (len(all_ids), n, kept_rows))            # also the barrier before stitching
+        summary["n_rows"], summary["n_hashed"] = sum(p[0] for p in parts), sum(p[1] for p in parts)
+        summary["kept_rows_written"] = sum(p[2] for p in parts) if args.write_shards else None
+        if rank == 0:
+            for name in ("clusters.jsonl", "removed_ids.txt", "kept_ids.txt"):
+                with open(os.path.join(args.output_dir, name), "wb") as out:
+                    for r in range(world):
+                        part = os.path.join(args.output_dir, name + ".part%05d" % r)
+                        with open(part, "rb") as f:
+                            out.write(f.read())
+                        os.remove(part)
+        dist.barrier()
+    if rank == 0:
+        with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
+            json.dump(summary, f)
+        print(json.dumps(summary), file=sys.stderr)
     return summary
 
 

@@ -126,13 +126,23 @@ def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: i
     """Multi-GPU path; every rank calls it with its own shard (documents doc_base ..
     doc_base+n_local of n_global).  Returns the same dict as dedup_local; labels cover all
     n_global documents (replicated), removed covers the local shard."""
+    if timer is not None:
+        timer.mark("start")
+    sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
+    if timer is not None:
+        timer.mark("signatures")
+    return cluster_distributed(be, sig, doc_base, n_global, bands, rows, key_bits, group, timings, timer)
+
+
+def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, bands: int = BANDS, rows: int = ROWS,
+                        key_bits: int = 64, group=None, timings: Optional[dict] = None, timer: Optional[StageTimer] = None):
+    """Multi-GPU clustering of signatures already in HBM (row i of `sig` = global document doc_base + i):
+    band records -> all-to-all by bucket owner -> local buckets -> spanning forest -> all-gather ->
+    replicated union-find.  Same return value as dedup_distributed."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    n_local = offsets.numel() - 1
+    n_local = sig.shape[0]
     mark = timer.mark if timer is not None else (lambda name: None)
-    mark("start")
-    sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
-    mark("signatures")
     key, meta = be.band_keys(sig, bands, rows, doc_base, key_bits)
     mark("band_keys")
     # --- route band records to their owner rank (all-to-all over xGMI)

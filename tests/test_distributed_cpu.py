@@ -63,3 +63,59 @@ def test_distributed_gloo_matches_oracle(tmp_path, mini_expected, world, bands, 
         sent += st["records_sent"]
         recv += st["records_received"]
     assert sent == recv == n * bands                      # every band record reaches exactly one owner
+
+
+CLI_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from cpu_backend import OracleBackend
+from map_neo_amd.cli import dedup as stage
+args = stage.build_parser().parse_args(["--input_dir", {inp!r}, "--output_dir", {out!r}, "--normalize", "none",
+                                        "--write_shards", "--workers", "2"])
+stage.run(args, engine_factory=lambda device: OracleBackend())
+'''
+
+
+def test_stage_cli_two_ranks_gloo(tmp_path, mini_docs):
+    """The stage entry point under torchrun with 2 ranks (oracle-backed CPU backend, gloo): every rank ingests
+    its block of shards; ids / clusters / surviving rows equal the single-process oracle result"""
+    import gzip
+    from oracle import ref_py as R
+    n = len(mini_docs)
+    ids = [f"id{(i * 37) % n:04d}" for i in range(n)]
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.mkdir()
+    bounds = [0, 40, 95, 150, n]
+    for f in range(4):
+        with open(inp / f"s{f}.jsonl", "w", encoding="utf8") as fh:
+            for i in range(bounds[f], bounds[f + 1]):
+                fh.write(json.dumps({"doc_id": ids[i], "raw_content": mini_docs[i]}, ensure_ascii=False) + "\n")
+    script = tmp_path / "cli_worker.py"
+    script.write_text(CLI_WORKER.format(root=ROOT, inp=str(inp), out=str(out)))
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lab = R.dedup(mini_docs)["labels"]
+    comp = {}
+    for k in range(n):
+        comp.setdefault(int(lab[k]), []).append(k)
+    exp_removed, exp_cluster = set(), {}
+    for members in comp.values():
+        if len(members) > 1:
+            keep = min(ids[k] for k in members)
+            for k in members:
+                exp_cluster[ids[k]] = keep
+                if ids[k] != keep:
+                    exp_removed.add(ids[k])
+    assert sorted(os.listdir(out)) == ["clusters.jsonl", "kept_ids.txt", "removed_ids.txt", "shards", "summary.json"]
+    assert set(open(out / "removed_ids.txt").read().split()) == exp_removed
+    kept = open(out / "kept_ids.txt").read().split()
+    assert set(kept) == set(ids) - exp_removed and len(kept) + len(exp_removed) == n
+    got = {c["doc_id"]: c["cluster"] for c in map(json.loads, open(out / "clusters.jsonl", encoding="utf8"))}
+    assert got == exp_cluster
+    rows = [json.loads(l) for p in sorted(os.listdir(out / "shards")) for l in gzip.open(out / "shards" / p, "rt", encoding="utf8")]
+    assert sorted(r["doc_id"] for r in rows) == sorted(set(ids) - exp_removed)
+    s = json.load(open(out / "summary.json"))
+    assert s["world"] == 2 and s["n_rows"] == n and s["n_removed_ids"] == len(exp_removed) and s["kept_rows_written"] == len(rows)

@@ -282,3 +282,29 @@ def test_exact_substr_dedup_cli(tmp_path, capsys):
     assert _read_parts(tmp_path / "o") == [{"doc_id": i, "raw_content": t} for i, t in exp]
     out = capsys.readouterr().out
     assert "the number of docs is  %d" % len(rows) in out and "the number of deduped docs is  %d" % len(exp) in out
+
+
+def test_stage_entry_point_distributed_one_rank(tmp_path, mini_docs):
+    """the multi-GPU code path of the stage CLI (RCCL all-to-all / all-gather) with a single rank == 1-GPU result"""
+    import subprocess
+    import sys
+    n = len(mini_docs)
+    ids = [f"id{(i * 37) % n:04d}" for i in range(n)]
+    inp = tmp_path / "in"
+    inp.mkdir()
+    for f, (a, b) in enumerate([(0, 70), (70, 140), (140, n)]):
+        _write_jsonl(inp / f"s{f}.jsonl", [{"doc_id": ids[i], "raw_content": mini_docs[i]} for i in range(a, b)])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode, extra in (("single", []), ("dist", ["--distributed"])):
+        out = tmp_path / mode
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-m", "map_neo_amd.cli.dedup", "--input_dir", str(inp), "--output_dir", str(out),
+                            "--normalize", "none", "--workers", "2"] + extra, capture_output=True, text=True, timeout=300,
+                           env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs[mode] = {name: open(out / name, encoding="utf8").read() for name in ("kept_ids.txt", "removed_ids.txt", "clusters.jsonl")}
+        assert sorted(os.listdir(out)) == ["clusters.jsonl", "kept_ids.txt", "removed_ids.txt", "summary.json"]
+    assert outs["single"] == outs["dist"]
+    lab = R.dedup(mini_docs)["labels"]
+    assert len(outs["dist"]["removed_ids.txt"].split()) == int((lab != np.arange(n)).sum())
