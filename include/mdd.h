@@ -186,6 +186,29 @@ int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
                     uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
                     uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
 
+/* Exact substring dedup.  Replaces text2hash + groupByKey +
+ * get_remove_list + remove_dup_content + the min_length filter of
+ * Matrix/english_data_clean_pipeline/dedup/Exact_Substring_Deduplication/exact_substr_dedup.py:34-47,
+ * 55-70,81-90 without materialising the windows.  Documents in input order (zipWithIndex, SUB:75).
+ *   mark:  dup[p] = 1 for every byte position p where a window of `window` code points starts
+ *          (offsets range(len - window), SUB:38) whose bytes already occur at a smaller position.
+ *          table: workspace u64[tab_size], tab_size >= 2 * number of windows (any size, not only
+ *          powers of two; sum over documents of max(0, bytes - window) is a safe window count);
+ *          dup: u8[text_bytes].  Both are cleared by the call.
+ *   count: kept_bytes[d] / kept_cps[d] = bytes / code points of document d that are covered by no
+ *          marked window (SUB:58-67).
+ *   write: the surviving bytes of every document with keep_doc[d] != 0 (the caller applies
+ *          SUB:90: kept_cps >= min_length) to out_text[out_offsets[d] ..); nothing is written at
+ *          or beyond out_capacity.
+ * 1 <= window <= 128; text 4-byte aligned with MDD_TEXT_PAD spare bytes, text_bytes < 2^40. */
+int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                    int window, uint64_t* table, uint64_t tab_size, uint8_t* dup);
+int mdd_substr_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                     int window, const uint8_t* dup, uint64_t* kept_bytes, uint64_t* kept_cps);
+int mdd_substr_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                     int window, const uint8_t* dup, const uint8_t* keep_doc, const uint64_t* out_offsets,
+                     uint8_t* out_text, uint64_t out_capacity);
+
 /* EN normalisation of pure-ASCII documents on the device.  Replaces
  * normalize_text EN:31-40 (fix_text/NFC: identity on clean ASCII; lower; delete
  * string.punctuation; strip; whitespace runs -> one space) for the documents where that needs no

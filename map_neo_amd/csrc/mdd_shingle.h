@@ -1,0 +1,254 @@
+// Shingle enumeration shared by the translation units that walk documents unit by unit
+// (mdd_hip.hip: sig_kernel; mdd_substr.hip: the sliding-window kernels of the exact substring stage).
+#ifndef MDD_SHINGLE_H
+#define MDD_SHINGLE_H
+
+#include "mdd_common.h"
+
+namespace {
+using namespace mddi;
+
+// Text access: `docw` is the (wave-uniform) aligned dword that contains the first byte of the
+// document; a shingle is addressed by p = byte offset from docw (32 bit).  Loads run up to
+// 80 bytes past the shingle start and are NOT clamped: the caller's allocation extends
+// MDD_TEXT_PAD bytes past text_bytes (include/mdd.h).
+struct TextView {
+    const uint32_t* docw;
+};
+
+__device__ __forceinline__ uint32_t ld_dword(const TextView& tv, uint32_t idx) { return tv.docw[idx]; }
+
+// ------------------------------------------------------------------------------------------
+// device: wave helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t y = (uint32_t)__shfl_xor((int)x, o, 64);
+        x = x > y ? x : y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ void wave_sync() {  // order this wave's LDS traffic (DS ops issue in order; this pins the compiler)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef MDD_WAVES
+#define MDD_WAVES 1
+#endif
+constexpr int WAVES = MDD_WAVES;  // waves (= documents in flight) per workgroup; 1 frees a wave slot as soon as its document ends
+constexpr int RING = 512;        // code-point / token boundary ring per wave (entries)
+constexpr uint64_t SEG_ITEM_CAP = 1u << 20;     // extra segments one mdd_signatures call can queue
+constexpr uint32_t SEG_BYTES_DEFAULT = 16384;   // documents longer than this are cut into segments
+constexpr uint32_t FAST_GUARD = 8u;
+
+struct __attribute__((aligned(16))) WaveLds {
+    uint32_t hbuf[64];     // shingle hashes of the current round
+    uint32_t ringS[RING];  // unit start offsets (doc-relative)
+    uint32_t ringE[RING];  // unit end offsets (word unit only)
+};
+
+// ------------------------------------------------------------------------------------------
+// Shingle enumeration shared by sig_kernel and the sliding-window kernels of the exact
+// substring stage: walks the units (code points / words) of segment [seg_beg, seg_end) of one
+// document in rounds of up to 64 shingles and calls visit(s, L, nvalid, n_done) once per
+// round; lane < nvalid holds shingle n_done + lane: s = its byte offset from tv.docw, L = its
+// length in bytes (lanes >= nvalid mirror a valid shingle).  Returns the number of shingles.
+// ------------------------------------------------------------------------------------------
+template <class Visit>
+__device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* text, uint64_t beg, uint32_t len, const TextView& tv,
+                                                   uint32_t boff, int unit, uint32_t width, bool ascii, bool split, uint32_t seg_beg,
+                                                   uint32_t seg_end, uint32_t lane, Visit&& visit) {
+    // ring state (wave-uniform)
+    uint32_t n_entS = 0, n_entE = 0, pos = seg_beg;
+    bool scan_done = false, seg_done = false;
+    // word unit: a segment that begins inside a token sees that token's END but not its
+    // START; drop that first end so that ringS[k] / ringE[k] keep describing the same token
+    bool skip_end = unit != MDD_UNIT_CHAR && seg_beg > 0 && seg_beg < len && text[beg + seg_beg - 1] != 0x20 &&
+                    text[beg + seg_beg] != 0x20;
+    const uint32_t look = unit == MDD_UNIT_CHAR ? width : width - 1;
+    uint32_t n_done = 0;
+    uint32_t ascii_total = 0;  // shingles of this segment when boundaries are implicit
+    if (ascii && len >= width) {
+        uint32_t j_end = len - width + 1 < seg_end ? len - width + 1 : seg_end;
+        ascii_total = j_end > seg_beg ? j_end - seg_beg : 0;
+    }
+    // boundary scan input: the scan window is 256 bytes, lane l owns the 4 bytes at pos + 4l, i.e. one
+    // unaligned dword = two coalesced aligned loads.  The next TWO windows are kept in flight in
+    // registers (a round of 64 word shingles consumes ~1.3 windows), so their latency hides behind the
+    // SHA-1 + permute work of the current round instead of stalling the ring fill.
+    uint32_t pfa_lo = 0, pfa_hi = 0, pfb_lo = 0, pfb_hi = 0;
+    auto window_load = [&](uint32_t wpos, uint32_t& lo, uint32_t& hi) {
+        uint32_t p0 = wpos + 4u * lane;
+        bool in = wpos < len && p0 < len;  // reads stay within 8 bytes of the document's end
+        uint32_t i = (boff + p0) >> 2;
+        lo = in ? tv.docw[i] : 0u;
+        hi = in ? tv.docw[i + 1] : 0u;
+    };
+    bool carry_sp = true;  // word unit: the byte before the scan window is a space (or the document starts)
+    if (!ascii) {
+        window_load(pos, pfa_lo, pfa_hi);
+        window_load(pos + 256u, pfb_lo, pfb_hi);
+        if (unit != MDD_UNIT_CHAR && pos > 0 && pos <= len) carry_sp = text[beg + pos - 1] == 0x20;
+    }
+
+    for (;;) {
+        uint32_t nvalid;
+        uint32_t s = 0;  // byte offset of the lane's shingle from tv.docw
+        uint32_t L = 0;
+        if (ascii) {
+            uint32_t rest = ascii_total - n_done;
+            nvalid = rest < 64u ? rest : 64u;
+            if (nvalid == 0) break;
+            uint32_t j = seg_beg + n_done + (lane < nvalid ? lane : 0u);
+            s = boff + j;
+            L = width;
+        } else {
+            // ---- fill the boundary ring until a full round is available or the doc ends
+            for (;;) {
+                uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
+                if (scan_done || n_ent - n_done >= 64u + look) break;
+                // window = doc-relative bytes [pos, pos+256); lane handles 4 of them
+                uint32_t p0 = pos + 4u * lane;
+                uint32_t w4 = __builtin_amdgcn_alignbyte(pfa_hi, pfa_lo, boff);  // bytes p0 .. p0+3
+                uint32_t nb = (pfa_hi >> (8u * boff)) & 0xFFu;                     // byte p0+4
+                pfa_lo = pfb_lo;
+                pfa_hi = pfb_hi;
+                window_load(pos + 512u, pfb_lo, pfb_hi);
+                uint32_t nval = p0 < len ? (len - p0 < 4u ? len - p0 : 4u) : 0u;
+                uint32_t fs = 0, fe = 0;
+                if (unit == MDD_UNIT_CHAR) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((uint32_t)k < nval && ((w4 >> (8 * k)) & 0xC0u) != 0x80u) fs |= 1u << k;
+                } else {
+                    bool spk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) spk[k] = (uint32_t)k < nval ? ((w4 >> (8 * k)) & 0xFFu) == 0x20u : true;
+                    bool next4 = p0 + 4u < len ? nb == 0x20u : true;
+                    uint32_t last = spk[3] ? 1u : 0u;
+                    uint32_t up = (uint32_t)__shfl_up((int)last, 1, 64);
+                    bool prev_sp = lane == 0 ? carry_sp : up != 0u;
+                    carry_sp = __builtin_amdgcn_readlane(last, 63) != 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        bool in = (uint32_t)k < nval;
+                        bool sp = spk[k];
+                        bool next_sp = k < 3 ? spk[k + 1] : next4;
+                        if (in && !sp && prev_sp) fs |= 1u << k;
+                        if (in && !sp && next_sp) fe |= 1u << k;
+                        prev_sp = sp;
+                    }
+                }
+                // ranks in byte order: 4 ballots (one per byte slot)
+                uint32_t rank_s = 0, tot_s = 0, rank_e = 0, tot_e = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint64_t bs = __ballot((fs >> k) & 1u);
+                    rank_s += below(bs);
+                    tot_s += (uint32_t)__popcll(bs);
+                    if (unit != MDD_UNIT_CHAR) {
+                        uint64_t be = __ballot((fe >> k) & 1u);
+                        rank_e += below(be);
+                        tot_e += (uint32_t)__popcll(be);
+                    }
+                }
+                uint32_t rs = n_entS + rank_s, re = rank_e;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((fs >> k) & 1u) lds.ringS[(rs++) & (RING - 1)] = p0 + k;
+                    if (unit != MDD_UNIT_CHAR && ((fe >> k) & 1u)) {
+                        uint32_t idx = re++;
+                        if (skip_end) {
+                            if (idx == 0) continue;
+                            idx -= 1;
+                        }
+                        lds.ringE[(n_entE + idx) & (RING - 1)] = p0 + k + 1;
+                    }
+                }
+                n_entS += tot_s;
+                if (skip_end && tot_e) {
+                    tot_e -= 1;
+                    skip_end = false;
+                }
+                n_entE += tot_e;
+                pos += 256u;
+                if (pos >= len) {
+                    scan_done = true;
+                    if (unit == MDD_UNIT_CHAR) {  // sentinel: end of the last code point
+                        if (lane == 0) lds.ringS[n_entS & (RING - 1)] = len;
+                        n_entS += 1;
+                    }
+                }
+            }
+            wave_sync();
+            uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
+            uint32_t rest = n_ent > n_done + look ? n_ent - look - n_done : 0u;
+            nvalid = rest < 64u ? rest : 64u;
+            if (nvalid == 0 || seg_done) break;
+            uint32_t j = n_done + (lane < nvalid ? lane : 0u);
+            uint32_t sb = lds.ringS[j & (RING - 1)];
+            uint32_t eb = unit == MDD_UNIT_CHAR ? lds.ringS[(j + look) & (RING - 1)]
+                                                : lds.ringE[(j + look) & (RING - 1)];
+            if (split) {  // units that start at or after seg_end belong to the next segment (starts ascend)
+                uint32_t nin = (uint32_t)__popcll(__ballot(lane < nvalid && sb < seg_end));
+                if (nin < nvalid) {
+                    seg_done = true;
+                    nvalid = nin;
+                    if (nvalid == 0) break;
+                    if (lane >= nvalid) {
+                        sb = lds.ringS[n_done & (RING - 1)];
+                        eb = unit == MDD_UNIT_CHAR ? lds.ringS[(n_done + look) & (RING - 1)]
+                                                   : lds.ringE[(n_done + look) & (RING - 1)];
+                    }
+                }
+            }
+            s = boff + sb;
+            L = eb - sb;
+        }
+
+        visit(s, L, nvalid, n_done);
+        n_done += nvalid;
+    }
+    return n_done;
+}
+
+// true when no byte the segment's shingles can touch is >= 0x80 (whole dwords are tested, so a neighbour's
+// non-ASCII byte may say "no": conservative)
+__device__ __forceinline__ bool segment_is_ascii(const TextView& tv, uint32_t boff, uint32_t len, uint32_t seg_beg, uint32_t seg_end,
+                                                 uint32_t width, uint32_t lane) {
+    uint32_t acc = 0;
+    if (len) {
+        uint32_t hi = (uint64_t)seg_end + width < len ? seg_end + width : len;
+        uint32_t d0 = (boff + seg_beg) >> 2, d1 = (boff + hi - 1u) >> 2;
+        for (uint32_t i = d0 + lane; i <= d1; i += 64) acc |= tv.docw[i];
+    }
+    return __ballot((acc & 0x80808080u) != 0u) == 0ull;
+}
+
+// One thread per document: documents longer than seg_bytes get their extra segments queued
+// and (sig != NULL) their signature row preset to 0xFFFFFFFF (their segments combine with atomicMin).
+__global__ void __launch_bounds__(256) seg_plan_kernel(const uint64_t* offsets, uint64_t n_docs, uint64_t text_bytes, uint32_t seg_bytes,
+                                                       uint64_t* items, unsigned long long* n_items, uint64_t max_items, uint32_t* sig,
+                                                       int K) {
+    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_docs) return;
+    uint64_t beg, end;
+    doc_range(offsets, d, text_bytes, beg, end);
+    uint64_t len = end - beg;
+    if (len <= seg_bytes) return;
+    uint64_t nseg = (len + seg_bytes - 1) / seg_bytes;
+    unsigned long long base = atomicAdd(n_items, (unsigned long long)(nseg - 1));
+    for (uint64_t k = 1; k < nseg; k++)
+        if (base + k - 1 < max_items) items[base + k - 1] = (d << 24) | k;
+    if (sig)
+        for (int q = 0; q < K; q++) sig[d * (uint64_t)K + q] = 0xFFFFFFFFu;
+}
+
+}  // namespace
+
+#endif  // MDD_SHINGLE_H

@@ -1,0 +1,298 @@
+// Exact substring dedup on the device.  Restates
+// Matrix/english_data_clean_pipeline/dedup/Exact_Substring_Deduplication/exact_substr_dedup.py
+//   :34-47  every window text[o : o+W] of W = 50 code points for o in range(len(text) - W) is hashed
+//           (SHA-256) and grouped; all occurrences but the first go to the remove list
+//   :55-70  a document loses every code point covered by one of its listed windows
+//   :90     documents left with fewer than min_length code points are dropped
+// without materialising the windows: the shingle walker of the MinHash kernel (mdd_shingle.h,
+// width = W) hands every wave 64 windows per round.
+//   win_kernel<false>  content key of each window -> open-addressing table of 8-byte entries
+//                      (24-bit tag | 40-bit byte position of the earliest window with these bytes).
+//                      A tag match is confirmed by comparing the bytes, so the table is exact:
+//                      no collision list, nothing for the host to resolve.  One random atomic per
+//                      window -- the device's random-atomic rate (~17 G/s on tables >> 256 MB,
+//                      tools/atomic_ubench.hip) bounds this pass.
+//   win_kernel<true>   same walk; a window whose table entry points at an earlier position sets
+//                      dup[its first byte] = 1.
+//   compact_kernel<false/true>  one wave per document, 64 bytes per step: a code point is gone
+//                      when one of the W code points ending at it starts a marked window; ballots
+//                      + popcounts give every byte its output position (count pass, caller's
+//                      prefix sum over documents, write pass).
+// Equal SHA-256 <=> equal bytes, so grouping on the bytes is the reference's grouping; "first" is
+// the smallest (document, offset) = smallest byte position.
+#include "mdd_shingle.h"
+
+namespace {
+
+constexpr unsigned long long EMPTY = ~0ULL;
+constexpr uint64_t POS_MASK = (1ULL << 40) - 1;
+
+struct WinArgs {
+    const uint8_t* text;
+    uint64_t text_bytes;
+    const uint64_t* offsets;
+    uint64_t n_docs;
+    uint32_t window;
+    uint32_t seg_bytes;
+    const uint64_t* items;
+    const uint64_t* n_items;
+    uint64_t max_items;
+    unsigned long long* work_counter;
+    unsigned long long* table;
+    uint64_t tab_size;
+    uint8_t* dup;
+};
+
+// 4 bytes at byte address p of the text (any alignment); reads at most 7 bytes past p
+__device__ __forceinline__ uint32_t ld4(const uint32_t* tw, uint64_t p) {
+    uint64_t i = p >> 2;
+    return __builtin_amdgcn_alignbyte(tw[i + 1], tw[i], (uint32_t)p & 3u);
+}
+
+// 64-bit content key of the L bytes at byte offset s from tv.docw
+__device__ __forceinline__ uint64_t window_key(const TextView& tv, uint32_t s, uint32_t L) {
+    uint32_t base = s >> 2, sh = s & 3u;
+    uint32_t h1 = 0x9E3779B9u ^ L, h2 = 0x85EBCA6Bu;
+    uint32_t lo = tv.docw[base];
+    uint32_t nd = (L + 3u) >> 2;
+    for (uint32_t k = 0; k < nd; k++) {
+        uint32_t hi = tv.docw[base + k + 1];
+        uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        uint32_t rem = L - 4u * k;
+        if (rem < 4u) w &= 0xFFFFFFFFu >> (8u * (4u - rem));
+        h1 = (h1 ^ w) * 0xCC9E2D51u;
+        h1 = __builtin_amdgcn_alignbit(h1, h1, 19);
+        h2 = (h2 + w) * 0x1B873593u;
+        h2 = __builtin_amdgcn_alignbit(h2, h2, 17) ^ h1;
+        lo = hi;
+    }
+    return mix64(((uint64_t)h1 << 32) | h2);
+}
+
+// the L bytes at text positions p and q are identical (q + L must not leave the text: checked by the caller)
+__device__ __forceinline__ bool same_bytes(const uint32_t* tw, uint64_t p, uint64_t q, uint32_t L) {
+    uint32_t nd = (L + 3u) >> 2;
+    for (uint32_t k = 0; k < nd; k++) {
+        uint32_t x = ld4(tw, p + 4u * k) ^ ld4(tw, q + 4u * k);
+        uint32_t rem = L - 4u * k;
+        if (rem < 4u) x &= 0xFFFFFFFFu >> (8u * (4u - rem));
+        if (x) return false;
+    }
+    return true;
+}
+
+template <bool LINK>
+__global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
+    __shared__ WaveLds lds;
+    const uint32_t lane = lane_id();
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(A.text);
+    const uint64_t extra = *A.n_items;  // final: seg_plan_kernel ran before this kernel on the stream
+    const uint64_t total = A.n_docs + (extra < A.max_items ? extra : A.max_items);
+    // persistent waves pulling documents (then queued segments of long documents) from one counter;
+    // every wave leaves once the counter passes `total`
+    auto fetch = [&]() -> uint64_t {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(A.work_counter, 1ull);
+        uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t item = fetch();
+    while (item < total) {
+        uint64_t next_item = fetch();
+        uint64_t d = item;
+        uint32_t seg = 0;
+        if (d >= A.n_docs) {
+            uint64_t it = A.items[d - A.n_docs];
+            d = it >> 24;
+            seg = (uint32_t)it & 0xFFFFFFu;
+        }
+        uint64_t beg, end;
+        doc_range(A.offsets, d, A.text_bytes, beg, end);
+        const uint32_t len = (uint32_t)(end - beg);
+        const bool split = len > A.seg_bytes;
+        const uint32_t seg_beg = seg * A.seg_bytes;
+        const uint32_t seg_end = (uint64_t)seg_beg + A.seg_bytes < len ? seg_beg + A.seg_bytes : len;
+        TextView tv;
+        tv.docw = tw + (beg >> 2);
+        const uint32_t boff = (uint32_t)beg & 3u;
+        const bool ascii = segment_is_ascii(tv, boff, len, seg_beg, seg_end, A.window, lane);
+        for_each_round(lds, A.text, beg, len, tv, boff, MDD_UNIT_CHAR, A.window, ascii, split, seg_beg, seg_end, lane,
+                       [&](uint32_t s, uint32_t L, uint32_t nvalid, uint32_t) {
+                           const uint32_t sb = s - boff;  // doc-relative first byte
+                           // SUB:38 range(len(text) - duplicate_len): the window that ends with the document is never hashed
+                           if (lane >= nvalid || sb + L >= len) return;
+                           const uint64_t pos = beg + sb;
+                           const uint64_t key = window_key(tv, s, L);
+                           const unsigned long long tag = (key & 0xFFFFFFull) << 40;
+                           const unsigned long long val = tag | pos;
+                           uint64_t slot = __umul64hi(key, A.tab_size);
+                           // the table is at most half full (caller's contract), so chains are short; the cap only keeps a
+                           // mis-sized table from spinning (windows past it are then treated as unique)
+                           const uint64_t max_probe = A.tab_size < 65536 ? A.tab_size : 65536;
+                           for (uint64_t probe = 0; probe < max_probe; probe++) {
+                               unsigned long long cur = LINK ? A.table[slot] : atomicCAS(&A.table[slot], EMPTY, val);
+                               if (cur == EMPTY || cur == val) return;  // claimed just now / this window is the entry
+                               uint64_t q = cur & POS_MASK;
+                               if ((cur & ~POS_MASK) == tag && q + L <= A.text_bytes && same_bytes(tw, pos, q, L)) {
+                                   if (LINK) {
+                                       if (q < pos) A.dup[pos] = 1;
+                                   } else if (cur > val) {
+                                       atomicMin(&A.table[slot], val);
+                                   }
+                                   return;
+                               }
+                               slot = slot + 1 == A.tab_size ? 0 : slot + 1;
+                           }
+                       });
+        item = next_item;
+    }
+}
+
+// One wave per document.  since = code points after the most recent marked window start (saturating;
+// "none yet" = huge); a code point is gone while since < W.  S / D / G: ballots of code-point starts,
+// marked starts and gone starts of the 64-byte step.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                      const uint64_t* __restrict__ offs, uint64_t n, const uint8_t* __restrict__ dup,
+                                                      uint32_t W, uint64_t* kept_bytes, uint64_t* kept_cps,
+                                                      const uint8_t* __restrict__ keep_doc, const uint64_t* __restrict__ out_offs,
+                                                      uint8_t* __restrict__ out_text, uint64_t out_cap) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t incl = lt | (1ULL << lane);
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        if (WRITE && !keep_doc[d]) continue;
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        const uint64_t o = WRITE ? out_offs[d] : 0;
+        uint64_t cnt_b = 0, cnt_c = 0;
+        uint32_t since = 0x7FFFFFFFu;
+        bool carry_gone = false;
+        for (uint64_t p = b; p < e; p += 64) {
+            const uint64_t i = p + lane;
+            const bool in = i < e;
+            const uint32_t c = in ? text[i] : 0x80u;
+            const bool start = in && (c & 0xC0u) != 0x80u;
+            const bool mark = start && dup[i] != 0;
+            const uint64_t S = __ballot(start), D = __ballot(mark);
+            const uint64_t Dq = D & incl;
+            uint32_t since_l;
+            if (Dq) {
+                uint32_t q = 63u - (uint32_t)__builtin_clzll(Dq);
+                since_l = (uint32_t)__builtin_popcountll(S & incl & ~(~0ULL >> (63u - q)));  // starts in (q, lane]
+            } else {
+                uint32_t add = (uint32_t)__builtin_popcountll(S & incl);
+                since_l = since > 0x7FFFFFFFu - add ? 0x7FFFFFFFu : since + add;
+            }
+            const uint64_t G = __ballot(start && since_l < W);
+            const uint64_t Sq = S & incl;
+            const bool gone = Sq ? ((G >> (63u - (uint32_t)__builtin_clzll(Sq))) & 1) : carry_gone;
+            const bool keep = in && !gone;
+            const uint64_t Kb = __ballot(keep);
+            if (WRITE && keep) {
+                uint64_t pos = o + cnt_b + __builtin_popcountll(Kb & lt);
+                if (pos < out_cap) out_text[pos] = (uint8_t)c;  // out_offsets are the caller's: stay inside out_text
+            }
+            cnt_b += __builtin_popcountll(Kb);
+            cnt_c += __builtin_popcountll(S & ~G);
+            if (D) {
+                uint32_t q = 63u - (uint32_t)__builtin_clzll(D);
+                since = (uint32_t)__builtin_popcountll(S & ~(~0ULL >> (63u - q)));
+            } else {
+                uint32_t add = (uint32_t)__builtin_popcountll(S);
+                since = since > 0x7FFFFFFFu - add ? 0x7FFFFFFFu : since + add;
+            }
+            if (S) carry_gone = (G >> (63u - (uint32_t)__builtin_clzll(S))) & 1;
+        }
+        if (!WRITE && lane == 0) {
+            kept_bytes[d] = cnt_b;
+            kept_cps[d] = cnt_c;
+        }
+    }
+}
+
+unsigned compact_grid(const mdd_ctx* ctx, uint64_t n) {
+    uint64_t blocks = (n + 3) / 4, cap = (uint64_t)ctx->cus * 64;
+    return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+}  // namespace
+
+extern "C" int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                               int window, uint64_t* table, uint64_t tab_size, uint8_t* dup) {
+    REQUIRE(ctx, "mdd_substr_mark: ctx is NULL");
+    REQUIRE(window >= 1 && window <= 128, "mdd_substr_mark: window=%d outside [1,128]", window);
+    REQUIRE(text_bytes < (1ULL << 40), "mdd_substr_mark: text_bytes exceeds 2^40");
+    if (n_docs == 0 || text_bytes == 0) return MDD_OK;
+    REQUIRE(text && offsets && table && dup, "mdd_substr_mark: NULL buffer");
+    REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_mark: text must be 4-byte aligned");
+    REQUIRE(tab_size >= 2, "mdd_substr_mark: tab_size=%llu too small", (unsigned long long)tab_size);
+    REQUIRE(n_docs < (1ull << 40), "mdd_substr_mark: n_docs too large");
+    HIP_TRY(hipSetDevice(ctx->device));
+    WinArgs A{};
+    A.text = text;
+    A.text_bytes = text_bytes;
+    A.offsets = offsets;
+    A.n_docs = n_docs;
+    A.window = (uint32_t)window;
+    uint64_t seg = ctx->seg_bytes;
+    uint64_t need = text_bytes / SEG_ITEM_CAP + 1;
+    if (seg < need) seg = need;
+    seg = (seg + 255) / 256 * 256;
+    REQUIRE(seg <= 0xFFFFFF00ull, "mdd_substr_mark: text too large for the segment plan");
+    uint64_t max_items = text_bytes / seg;
+    if (max_items > SEG_ITEM_CAP) max_items = SEG_ITEM_CAP;
+    A.seg_bytes = (uint32_t)seg;
+    A.items = ctx->seg_items;
+    A.n_items = ctx->seg_n_items;
+    A.max_items = max_items;
+    A.work_counter = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 1);
+    A.table = reinterpret_cast<unsigned long long*>(table);
+    A.tab_size = tab_size;
+    A.dup = dup;
+    HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
+    HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, ctx->stream));
+    uint64_t waves = (uint64_t)ctx->cus * 4 * 8;
+    if (waves > n_docs + max_items) waves = n_docs + max_items;
+    for (int pass = 0; pass < 2; pass++) {
+        HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));
+        hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes,
+                           A.seg_bytes, ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items,
+                           (uint32_t*)nullptr, 0);
+        HIP_TRY(hipGetLastError());
+        if (pass == 0) hipLaunchKernelGGL(win_kernel<false>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, A);
+        else hipLaunchKernelGGL(win_kernel<true>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, A);
+        HIP_TRY(hipGetLastError());
+    }
+    return MDD_OK;
+}
+
+extern "C" int mdd_substr_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                                int window, const uint8_t* dup, uint64_t* kept_bytes, uint64_t* kept_cps) {
+    REQUIRE(ctx, "mdd_substr_count: ctx is NULL");
+    REQUIRE(window >= 1 && window <= 128, "mdd_substr_count: window=%d outside [1,128]", window);
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && kept_bytes && kept_cps && ((text && dup) || text_bytes == 0), "mdd_substr_count: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(compact_kernel<false>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                       n_docs, dup, (uint32_t)window, kept_bytes, kept_cps, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
+                       (uint8_t*)nullptr, (uint64_t)0);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+extern "C" int mdd_substr_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                                int window, const uint8_t* dup, const uint8_t* keep_doc, const uint64_t* out_offsets,
+                                uint8_t* out_text, uint64_t out_capacity) {
+    REQUIRE(ctx, "mdd_substr_write: ctx is NULL");
+    REQUIRE(window >= 1 && window <= 128, "mdd_substr_write: window=%d outside [1,128]", window);
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && keep_doc && out_offsets && ((text && dup && out_text) || text_bytes == 0), "mdd_substr_write: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(compact_kernel<true>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                       n_docs, dup, (uint32_t)window, (uint64_t*)nullptr, (uint64_t*)nullptr, keep_doc, out_offsets, out_text,
+                       out_capacity);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}

@@ -179,12 +179,17 @@ def paragraph_dedup(eng: Engine, rows: Sequence[Tuple[object, Optional[str]]], m
 # exact substring dedup
 # ------------------------------------------------------------------------------------------
 def exact_substr_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, duplicate_len: int = 50,
-                              min_length: int = 20, key_bits: int = 64):
+                              min_length: int = 20, key_bits: int = 64, fused: bool = True):
     """Documents in input order (SUB:75 zipWithIndex).  Returns (text', offsets', kept document
     indices): every window of duplicate_len code points starting at offsets
     range(len - duplicate_len) (SUB:38) that already occurred at a smaller (document, offset) has
     its code points deleted (SUB:44-47,58-67); documents left with fewer than min_length code
-    points are dropped (SUB:90)."""
+    points are dropped (SUB:90).
+    fused (default): the dedicated kernels (`mdd_substr_mark/count/write`: windows are never materialised,
+    exact table, no torch index plumbing).  fused=False: the generic route through `mdd_exact_group` with
+    explicit unit ranges (kept as an independent implementation for cross-checks; honours key_bits)."""
+    if fused and key_bits == 64 and 1 <= duplicate_len <= 128:
+        return eng.substr_dedup(text, offs, duplicate_len, min_length)
     dev = text.device
     nd = offs.numel() - 1
     total = int(offs[-1].item()) if nd > 0 else 0
@@ -222,10 +227,10 @@ def exact_substr_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tenso
 
 
 def exact_substr_dedup(eng: Engine, rows: Sequence[Tuple[Optional[str], object]], duplicate_len: int = 50,
-                       min_length: int = 20, key_bits: int = 64) -> List[Tuple[object, str]]:
+                       min_length: int = 20, key_bits: int = 64, fused: bool = True) -> List[Tuple[object, str]]:
     """(ori_doc_id, cleaned text) for documents that keep at least min_length characters."""
     if not rows:
         return []
     buf, offs = pack_texts([t for t, _ in rows])
-    t, o, docs = exact_substr_dedup_packed(eng, eng.to_device(buf), eng.to_device(offs), duplicate_len, min_length, key_bits)
+    t, o, docs = exact_substr_dedup_packed(eng, eng.to_device(buf), eng.to_device(offs), duplicate_len, min_length, key_bits, fused)
     return [(rows[d][1], s) for d, s in zip(docs.cpu().tolist(), _decode(t, o))]

@@ -33,6 +33,9 @@ SIGNATURES = {
     "mdd_components_finish": (_int, [_vp, _vp, _u64]),
     "mdd_forest_edges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _vp]),
     "mdd_removed_mask": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
+    "mdd_substr_mark": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _u64, _vp]),
+    "mdd_substr_count": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp]),
+    "mdd_substr_write": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp, _vp, _u64]),
     "mdd_normalize_en_count": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp]),
     "mdd_normalize_en_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _u64]),
     "mdd_exact_group": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _vp, _vp, _u64, _vp]),

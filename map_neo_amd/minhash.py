@@ -274,6 +274,37 @@ class Engine:
         self.last_exact_collisions = n_coll
         return first_of
 
+    def substr_dedup(self, text: torch.Tensor, offsets: torch.Tensor, window: int = 50, min_length: int = 20):
+        """Exact substring dedup of a packed corpus (SUB:34-95).  Returns (out_text uint8 [padded],
+        out_offsets int64 [n_kept+1], kept document indices int64)."""
+        n = offsets.numel() - 1
+        if n <= 0:
+            return (torch.zeros(padded_size(0), dtype=torch.uint8, device=self.device),
+                    torch.zeros(1, dtype=torch.int64, device=self.device), torch.zeros(0, dtype=torch.int64, device=self.device))
+        text_bytes = max(0, text.numel() - TEXT_PAD)
+        lens = offsets[1:] - offsets[:-1]
+        n_win = int(torch.clamp(lens - window, min=0).sum().item())        # code points <= bytes: an upper bound
+        table = self.empty(max(2, 2 * n_win), torch.int64)
+        dup = self.empty(max(1, text_bytes), torch.uint8)
+        _lib.check(self.L.mdd_substr_mark(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(table), table.numel(),
+                                          _ptr(dup)), "mdd_substr_mark")
+        del table
+        kept_b = torch.zeros(n, dtype=torch.int64, device=self.device)
+        kept_c = torch.zeros(n, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.mdd_substr_count(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(dup), _ptr(kept_b),
+                                           _ptr(kept_c)), "mdd_substr_count")
+        keep_doc = kept_c >= min_length
+        out_offs_all = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(kept_b * keep_doc, 0, out=out_offs_all[1:])
+        total = int(out_offs_all[-1].item())
+        out_text = torch.zeros(padded_size(total), dtype=torch.uint8, device=self.device)
+        keep_u8 = keep_doc.to(torch.uint8)
+        _lib.check(self.L.mdd_substr_write(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(dup), _ptr(keep_u8),
+                                           _ptr(out_offs_all), _ptr(out_text), total), "mdd_substr_write")
+        docs = torch.nonzero(keep_doc).flatten()
+        out_offs = torch.cat([out_offs_all[:-1][docs], out_offs_all[-1:]])
+        return out_text, out_offs, docs
+
     def normalize_en(self, text: torch.Tensor, offsets: torch.Tensor):
         """EN:31-40 on the pure-ASCII documents of a packed batch, on the device.  Returns
         (out_text uint8 [padded], out_offsets int64 [n+1], non_ascii uint8 [n]); documents with

@@ -66,8 +66,8 @@ def test_paragraph_dedup(engine, key_bits):
     assert 0 < len(got) < len(rows)
 
 
-@pytest.mark.parametrize("key_bits", [64, 7])
-def test_exact_substr_dedup(engine, key_bits):
+@pytest.mark.parametrize("key_bits,fused", [(64, True), (64, False), (7, False)])
+def test_exact_substr_dedup(engine, key_bits, fused):
     rng = np.random.Generator(np.random.PCG64(6))
     base = ["".join(chr(int(c)) for c in rng.integers(0x61, 0x7B, 400)) for _ in range(12)]
     zh = ["".join(chr(int(c)) for c in rng.integers(0x4E00, 0x4F00, 200)) for _ in range(6)]
@@ -80,7 +80,7 @@ def test_exact_substr_dedup(engine, key_bits):
             parts.append(src[a:a + int(rng.integers(30, 150))])
         rows.append((" 😀 ".join(parts), f"id{i}"))
     rows += [("short text", "s1"), ("", "s2"), ("x" * 50, "s3"), ("y" * 51, "s4"), ("y" * 120, "s5")]
-    got = exact.exact_substr_dedup(engine, rows, 50, 20, key_bits=key_bits)
+    got = exact.exact_substr_dedup(engine, rows, 50, 20, key_bits=key_bits, fused=fused)
     exp = RX.exact_substr_dedup(rows, 50, 20)
     assert got == exp
     assert sum(len(t) for _, t in got) < sum(len(t) for t, _ in rows)
@@ -102,4 +102,25 @@ def test_paragraph_and_substr_edge_cases(engine):
     ]
     for rows in sub:
         for dl, ml in ((50, 20), (5, 0), (50, 0)):
-            assert exact.exact_substr_dedup(engine, rows, dl, ml) == RX.exact_substr_dedup(rows, dl, ml), (rows, dl, ml)
+            for fused in (True, False):
+                assert exact.exact_substr_dedup(engine, rows, dl, ml, fused=fused) == RX.exact_substr_dedup(rows, dl, ml), (rows, dl, ml, fused)
+
+
+def test_exact_substr_dedup_long_and_mixed_documents(engine):
+    """fused kernels: documents longer than a segment (split across waves), multi-byte text, many repeats"""
+    rng = np.random.Generator(np.random.PCG64(9))
+    alpha = [chr(c) for c in range(0x61, 0x7B)] + [" "] * 5 + ["é", "数", "据", "😀"]
+    blocks = ["".join(rng.choice(alpha, int(rng.integers(40, 400)))) for _ in range(30)]
+    rows = []
+    for i in range(40):
+        k = int(rng.integers(1, 12)) if i % 8 else int(rng.integers(150, 260))     # every 8th document is long (> 16 KiB)
+        rows.append(("".join(rng.choice(blocks, k)), i))
+    try:
+        engine.set_segment_bytes(1024)
+        small_seg = exact.exact_substr_dedup(engine, rows, 50, 20)
+    finally:
+        engine.set_segment_bytes(0)
+    got = exact.exact_substr_dedup(engine, rows, 50, 20)
+    exp = RX.exact_substr_dedup(rows, 50, 20)
+    assert got == exp and small_seg == exp
+    assert exact.exact_substr_dedup(engine, rows, 50, 20, fused=False) == exp
