@@ -156,7 +156,10 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
     out["paragraph_dedup"] = {"ms": ms, "docs_per_s": n / ms * 1e3, "text_gb_per_s": text_bytes / ms / 1e6, "paragraphs": n_par,
                               "bytes_out": int(po[-1].item()), "docs_out": int(pd.numel()),
                               "algorithmic_bytes": 2 * text_bytes + int(po[-1].item()) + 36 * n_par,
-                              "hbm_frac": (2 * text_bytes + int(po[-1].item()) + 36 * n_par) / ms / 1e6 / HBM}
+                              "hbm_frac": (2 * text_bytes + int(po[-1].item()) + 36 * n_par) / ms / 1e6 / HBM,
+                              "note": "algorithmic = text read to cut + to hash, survivors written, 36 B of unit ranges / keys / "
+                                      "table per paragraph; the implementation reads the text 5 times (count, units, hash, "
+                                      "compact count, compact write)"}
     if with_cpu:
         from oracle import ref_exact
         k = 20000

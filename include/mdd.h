@@ -186,6 +186,28 @@ int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
                     uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
                     uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
 
+/* Paragraph dedup.  Replaces paragraph_dedup of
+ * Matrix/english_data_clean_pipeline/dedup/Paragraph_Deduplication/paragraph.py:15-30 around
+ * mdd_exact_group; documents in (doc_id, then input) order, a paragraph = a "\n"-separated piece.
+ *   count:   units_per_doc[d] = paragraphs of document d (PAR:16-17 split + posexplode)
+ *   units:   byte ranges ubeg/uend of all paragraphs; unit_base[d] = exclusive prefix sum of
+ *            units_per_doc (u64[n_docs]), n_units their total.  mdd_exact_group on these ranges is
+ *            PAR:18-23 (first_of[u] == u <=> the paragraph survives).
+ *   compact_count: kept_bytes[d] / kept_cps[d] = bytes / code points of "\n".join(surviving
+ *            paragraphs of d) (PAR:26-27), has_unit[d] = 1 when at least one survives;
+ *   compact_write: that text for every document with keep_doc[d] != 0 (the caller applies PAR:29) at
+ *            out_text[out_offsets[d] ..); nothing is written at or beyond out_capacity. */
+int mdd_para_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                   uint64_t* units_per_doc);
+int mdd_para_units(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                   const uint64_t* unit_base, uint64_t n_units, uint64_t* ubeg, uint64_t* uend);
+int mdd_para_compact_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                           const uint64_t* unit_base, uint64_t n_units, const uint32_t* first_of, uint64_t* kept_bytes,
+                           uint64_t* kept_cps, uint8_t* has_unit);
+int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                           const uint64_t* unit_base, uint64_t n_units, const uint32_t* first_of, const uint8_t* keep_doc,
+                           const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity);
+
 /* Exact substring dedup.  Replaces text2hash + groupByKey +
  * get_remove_list + remove_dup_content + the min_length filter of
  * Matrix/english_data_clean_pipeline/dedup/Exact_Substring_Deduplication/exact_substr_dedup.py:34-47,

@@ -1,0 +1,167 @@
+// Paragraph dedup on the device.  Restates
+// Matrix/english_data_clean_pipeline/dedup/Paragraph_Deduplication/paragraph.py
+//   :16-17  split(content, "\n") + posexplode            -> para_count / para_units: unit ranges per document
+//   :18-23  sha2(paragraph) + row_number over (id, pos)   -> mdd_exact_group on those ranges (first_of)
+//   :26-27  collect_list ordered by pos + concat_ws("\n") -> para_compact<count/write>
+//   :29     length >= min_len                             -> caller, from kept_cps
+// One wave per document, 64 bytes per step; a byte's paragraph index is unit_base[d] + the
+// newlines before it, so ballots + popcounts place every unit boundary and every surviving byte
+// without scans or LDS.  HBM-bound: the text is read four times (count, units, compact count,
+// compact write) and the survivors written once.
+#include "mdd_common.h"
+
+namespace {
+using namespace mddi;
+
+unsigned wave_grid(const mdd_ctx* ctx, uint64_t n) {
+    uint64_t blocks = (n + 3) / 4, cap = (uint64_t)ctx->cus * 64;
+    return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+// UNITS = false: units_per_doc[d] = newlines + 1.  UNITS = true: ubeg / uend of every paragraph.
+template <bool UNITS>
+__global__ void __launch_bounds__(256) para_scan_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                        const uint64_t* __restrict__ offs, uint64_t n, uint64_t* units_per_doc,
+                                                        const uint64_t* __restrict__ unit_base, uint64_t n_units, uint64_t* ubeg,
+                                                        uint64_t* uend) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        uint64_t u = UNITS ? unit_base[d] : 0;  // paragraph that holds the first byte of the step
+        uint64_t nl = 0;
+        if (UNITS && lane == 0 && u < n_units) ubeg[u] = b;
+        for (uint64_t p = b; p < e; p += 64) {
+            const uint64_t i = p + lane;
+            const bool is_nl = i < e && text[i] == 10u;
+            const uint64_t N = __ballot(is_nl);
+            if (UNITS && is_nl) {
+                uint64_t mine = u + __builtin_popcountll(N & lt);  // the paragraph this newline ends
+                if (mine + 1 < n_units) {                          // unit_base is the caller's: stay inside ubeg / uend
+                    uend[mine] = i;
+                    ubeg[mine + 1] = i + 1;
+                }
+            }
+            uint64_t c = __builtin_popcountll(N);
+            u += c;
+            nl += c;
+        }
+        if (UNITS) {
+            if (lane == 0 && u < n_units) uend[u] = e;
+        } else if (lane == 0) {
+            units_per_doc[d] = nl + 1;
+        }
+    }
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) para_compact_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                           const uint64_t* __restrict__ offs, uint64_t n,
+                                                           const uint64_t* __restrict__ unit_base, uint64_t n_units,
+                                                           const uint32_t* __restrict__ first_of, uint64_t* kept_bytes,
+                                                           uint64_t* kept_cps, uint8_t* has_unit, const uint8_t* __restrict__ keep_doc,
+                                                           const uint64_t* __restrict__ out_offs, uint8_t* __restrict__ out_text,
+                                                           uint64_t out_cap) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t incl = lt | (1ULL << lane);
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    auto kept_unit = [&](uint64_t u) -> bool { return u < n_units && first_of[u] == (uint32_t)u; };
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        if (WRITE && !keep_doc[d]) continue;
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        const uint64_t o = WRITE ? out_offs[d] : 0;
+        uint64_t u = unit_base[d];
+        uint64_t cnt_b = 0, cnt_c = 0;
+        bool any = false;  // a paragraph that ended before this step survives
+        for (uint64_t p = b; p < e; p += 64) {
+            const uint64_t i = p + lane;
+            const bool in = i < e;
+            const uint32_t c = in ? text[i] : 0u;
+            const bool is_nl = in && c == 10u;
+            const uint64_t N = __ballot(is_nl);
+            const uint64_t mine = u + __builtin_popcountll(N & lt);  // paragraph of this byte (a newline belongs to the one it ends)
+            const bool ku = in && kept_unit(mine);
+            const uint64_t Kn = __ballot(is_nl && ku);               // newlines that end a surviving paragraph
+            bool keep;
+            if (is_nl)  // the "\n" in front of a surviving paragraph that is not its document's first survivor
+                keep = kept_unit(mine + 1) && (any || (Kn & incl) != 0);
+            else
+                keep = ku;
+            const uint64_t Kb = __ballot(keep);
+            if (WRITE && keep) {
+                uint64_t pos = o + cnt_b + __builtin_popcountll(Kb & lt);
+                if (pos < out_cap) out_text[pos] = (uint8_t)c;
+            }
+            cnt_b += __builtin_popcountll(Kb);
+            cnt_c += __builtin_popcountll(__ballot(keep && (c & 0xC0u) != 0x80u));
+            any = any || Kn != 0;
+            u += __builtin_popcountll(N);
+        }
+        if (!WRITE && lane == 0) {
+            kept_bytes[d] = cnt_b;
+            kept_cps[d] = cnt_c;
+            has_unit[d] = any || kept_unit(u);  // u = the document's last paragraph
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mdd_para_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                              uint64_t* units_per_doc) {
+    REQUIRE(ctx, "mdd_para_count: ctx is NULL");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && units_per_doc && (text || text_bytes == 0), "mdd_para_count: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(para_scan_kernel<false>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                       n_docs, units_per_doc, (const uint64_t*)nullptr, (uint64_t)0, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+extern "C" int mdd_para_units(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                              const uint64_t* unit_base, uint64_t n_units, uint64_t* ubeg, uint64_t* uend) {
+    REQUIRE(ctx, "mdd_para_units: ctx is NULL");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && unit_base && ubeg && uend && (text || text_bytes == 0), "mdd_para_units: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(para_scan_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                       n_docs, (uint64_t*)nullptr, unit_base, n_units, ubeg, uend);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+extern "C" int mdd_para_compact_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
+                                      uint64_t n_docs, const uint64_t* unit_base, uint64_t n_units, const uint32_t* first_of,
+                                      uint64_t* kept_bytes, uint64_t* kept_cps, uint8_t* has_unit) {
+    REQUIRE(ctx, "mdd_para_compact_count: ctx is NULL");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && unit_base && first_of && kept_bytes && kept_cps && has_unit && (text || text_bytes == 0),
+            "mdd_para_compact_count: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(para_compact_kernel<false>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                       n_docs, unit_base, n_units, first_of, kept_bytes, kept_cps, has_unit, (const uint8_t*)nullptr,
+                       (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+extern "C" int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
+                                      uint64_t n_docs, const uint64_t* unit_base, uint64_t n_units, const uint32_t* first_of,
+                                      const uint8_t* keep_doc, const uint64_t* out_offsets, uint8_t* out_text,
+                                      uint64_t out_capacity) {
+    REQUIRE(ctx, "mdd_para_compact_write: ctx is NULL");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && unit_base && first_of && keep_doc && out_offsets && ((text && out_text) || text_bytes == 0),
+            "mdd_para_compact_write: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(para_compact_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                       n_docs, unit_base, n_units, first_of, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr, keep_doc,
+                       out_offsets, out_text, out_capacity);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}

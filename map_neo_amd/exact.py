@@ -109,12 +109,17 @@ def exact_document_dedup(eng: Engine, contents: Sequence[Optional[str]], key_bit
 # ------------------------------------------------------------------------------------------
 # paragraph dedup
 # ------------------------------------------------------------------------------------------
-def paragraph_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, min_len: int = 20, key_bits: int = 64):
+def paragraph_dedup_packed(eng: Engine, text: torch.Tensor, offs: torch.Tensor, min_len: int = 20, key_bits: int = 64,
+                           fused: bool = True):
     """Documents in (id, then input) order.  Returns (text', offsets', kept document indices):
     every paragraph ("\\n"-separated, PAR:16-17) that already occurred earlier -- in an earlier
     document or earlier in the same one -- is dropped (PAR:18-23), the survivors of a document are
     re-joined with "\\n" (PAR:26-27), documents left without a paragraph or with fewer than
-    min_len code points are dropped (PAR:29)."""
+    min_len code points are dropped (PAR:29).
+    fused (default): `mdd_para_*` kernels cut and re-join the paragraphs around `mdd_exact_group`;
+    fused=False: the same steps as torch index plumbing (independent implementation for cross-checks)."""
+    if fused:
+        return eng.paragraph_dedup(text, offs, min_len, key_bits)
     dev = text.device
     nd = offs.numel() - 1
     total = int(offs[-1].item()) if nd > 0 else 0
@@ -164,14 +169,14 @@ def _decode(out_text, out_offs) -> List[str]:
 
 
 def paragraph_dedup(eng: Engine, rows: Sequence[Tuple[object, Optional[str]]], min_len: int = 20,
-                    key_bits: int = 64) -> List[Tuple[object, str]]:
+                    key_bits: int = 64, fused: bool = True) -> List[Tuple[object, str]]:
     """(id, text) per surviving document, sorted by id.  Ids must be unique and mutually comparable
     (the reference would merge the rows of a repeated id, PAR:26)."""
     rows = sorted(((rid, c) for rid, c in rows if c is not None), key=lambda r: r[0])
     if not rows:
         return []
     buf, offs = pack_texts([c for _, c in rows])
-    t, o, docs = paragraph_dedup_packed(eng, eng.to_device(buf), eng.to_device(offs), min_len, key_bits)
+    t, o, docs = paragraph_dedup_packed(eng, eng.to_device(buf), eng.to_device(offs), min_len, key_bits, fused)
     return [(rows[d][0], s) for d, s in zip(docs.cpu().tolist(), _decode(t, o))]
 
 

@@ -33,6 +33,10 @@ SIGNATURES = {
     "mdd_components_finish": (_int, [_vp, _vp, _u64]),
     "mdd_forest_edges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _vp]),
     "mdd_removed_mask": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
+    "mdd_para_count": (_int, [_vp, _vp, _u64, _vp, _u64, _vp]),
+    "mdd_para_units": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "mdd_para_compact_count": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "mdd_para_compact_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _u64]),
     "mdd_substr_mark": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _u64, _vp]),
     "mdd_substr_count": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp]),
     "mdd_substr_write": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp, _vp, _u64]),

@@ -274,6 +274,46 @@ class Engine:
         self.last_exact_collisions = n_coll
         return first_of
 
+    def paragraph_dedup(self, text: torch.Tensor, offsets: torch.Tensor, min_len: int = 20, key_bits: int = 64):
+        """Paragraph dedup of a packed corpus (PAR:15-30), documents in (id, input) order.  Returns
+        (out_text uint8 [padded], out_offsets int64 [n_kept+1], kept document indices int64)."""
+        n = offsets.numel() - 1
+        if n <= 0:
+            return (torch.zeros(padded_size(0), dtype=torch.uint8, device=self.device),
+                    torch.zeros(1, dtype=torch.int64, device=self.device), torch.zeros(0, dtype=torch.int64, device=self.device))
+        text_bytes = max(0, text.numel() - TEXT_PAD)
+        per_doc = torch.zeros(n, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.mdd_para_count(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(per_doc)), "mdd_para_count")
+        base = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(per_doc, 0, out=base[1:])
+        n_units = int(base[-1].item())
+        ubeg = self.empty(n_units, torch.int64)
+        uend = self.empty(n_units, torch.int64)
+        _lib.check(self.L.mdd_para_units(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(base), n_units, _ptr(ubeg),
+                                         _ptr(uend)), "mdd_para_units")
+        first_of = self.exact_group(text, ubeg, uend, key_bits)
+        del ubeg, uend
+        kept_b = torch.zeros(n, dtype=torch.int64, device=self.device)
+        kept_c = torch.zeros(n, dtype=torch.int64, device=self.device)
+        has_unit = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.mdd_para_compact_count(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(base), n_units,
+                                                 _ptr(first_of), _ptr(kept_b), _ptr(kept_c), _ptr(has_unit)),
+                   "mdd_para_compact_count")
+        keep_doc = has_unit != 0
+        if min_len > 0:
+            keep_doc &= kept_c >= min_len
+        out_offs_all = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(kept_b * keep_doc, 0, out=out_offs_all[1:])
+        total = int(out_offs_all[-1].item())
+        out_text = torch.zeros(padded_size(total), dtype=torch.uint8, device=self.device)
+        keep_u8 = keep_doc.to(torch.uint8)
+        _lib.check(self.L.mdd_para_compact_write(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(base), n_units,
+                                                 _ptr(first_of), _ptr(keep_u8), _ptr(out_offs_all), _ptr(out_text), total),
+                   "mdd_para_compact_write")
+        docs = torch.nonzero(keep_doc).flatten()
+        out_offs = torch.cat([out_offs_all[:-1][docs], out_offs_all[-1:]])
+        return out_text, out_offs, docs
+
     def substr_dedup(self, text: torch.Tensor, offsets: torch.Tensor, window: int = 50, min_length: int = 20):
         """Exact substring dedup of a packed corpus (SUB:34-95).  Returns (out_text uint8 [padded],
         out_offsets int64 [n_kept+1], kept document indices int64)."""

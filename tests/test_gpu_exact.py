@@ -53,14 +53,14 @@ def test_exact_document_dedup(engine):
     assert 0 < keep.sum() < len(docs)
 
 
-@pytest.mark.parametrize("key_bits", [64, 5])
-def test_paragraph_dedup(engine, key_bits):
+@pytest.mark.parametrize("key_bits,fused", [(64, True), (5, True), (64, False), (5, False)])
+def test_paragraph_dedup(engine, key_bits, fused):
     rng = np.random.Generator(np.random.PCG64(5))
     docs = _corpus(rng, 300)
     ids = [f"doc-{int(i):05d}" for i in rng.permutation(len(docs))]
     rows = list(zip(ids, docs))
     rows[11] = (rows[11][0], None)
-    got = exact.paragraph_dedup(engine, rows, min_len=20, key_bits=key_bits)
+    got = exact.paragraph_dedup(engine, rows, min_len=20, key_bits=key_bits, fused=fused)
     exp = RX.paragraph_dedup(rows, min_len=20)
     assert got == exp
     assert 0 < len(got) < len(rows)
@@ -95,7 +95,9 @@ def test_paragraph_and_substr_edge_cases(engine):
     ]
     for rows in cases:
         for min_len in (0, 3, 20):
-            assert exact.paragraph_dedup(engine, rows, min_len=min_len) == RX.paragraph_dedup(rows, min_len=min_len), (rows, min_len)
+            for fused in (True, False):
+                assert exact.paragraph_dedup(engine, rows, min_len=min_len, fused=fused) == RX.paragraph_dedup(rows, min_len=min_len), \
+                    (rows, min_len, fused)
     sub = [
         [("", "a")], [("x" * 50, "a")], [("x" * 51, "a")], [("x" * 52, "a")], [("ab" * 60, "a"), ("ab" * 60, "b")],
         [("é" * 120, "a")], [("0123456789" * 6, "a"), ("z" + "0123456789" * 6, "b"), ("0123456789" * 5 + "0", "c")], [],
