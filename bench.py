@@ -213,6 +213,12 @@ def main():
                     help="use the multi-GPU path (RCCL all-to-all / all-gather) even with one rank")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner to
+    # fd 1 from C code), so fd 1 is pointed at stderr for the whole run and the result goes to the saved fd.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -389,7 +395,8 @@ def main():
         if args.stages and world == 1:
             del out
             res["next_rows"] = stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=not args.no_cpu)
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
