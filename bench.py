@@ -180,9 +180,10 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
     ms, (st, so2, sd) = timed(lambda: exact.exact_substr_dedup_packed(eng, text, so, 50, 20), reps=1)
     out["exact_substr_dedup"] = {"ms": ms, "docs": k, "docs_per_s": k / ms * 1e3, "text_gb_per_s": sb / ms / 1e6,
                                  "windows_per_s": (sb - 50 * k) / ms * 1e3, "bytes_out": int(so2[-1].item()), "docs_out": int(sd.numel()),
-                                 "random_table_ops": 2 * (sb - 50 * k),
-                                 "note": "bound by the device's random 8-byte atomic / load rate (~17 G/s and ~50 G/s on "
-                                         "tables >> 256 MB, tools/atomic_ubench.hip): one of each per window"}
+                                 "random_atomics": sb - 50 * k,
+                                 "atomic_floor_ms": (sb - 50 * k) / 17.5e9 * 1e3,
+                                 "note": "one random 8-byte atomicCAS per window; the device sustains ~17.5 G/s of those on "
+                                         "tables >> 256 MB (tools/atomic_ubench.hip), which bounds the stage"}
     if with_cpu:
         from oracle import ref_exact
         k = 1500

@@ -6,14 +6,15 @@
 //   :90     documents left with fewer than min_length code points are dropped
 // without materialising the windows: the shingle walker of the MinHash kernel (mdd_shingle.h,
 // width = W) hands every wave 64 windows per round.
-//   win_kernel<false>  content key of each window -> open-addressing table of 8-byte entries
+//   win_kernel         content key of each window -> open-addressing table of 8-byte entries
 //                      (24-bit tag | 40-bit byte position of the earliest window with these bytes).
 //                      A tag match is confirmed by comparing the bytes, so the table is exact:
-//                      no collision list, nothing for the host to resolve.  One random atomic per
-//                      window -- the device's random-atomic rate (~17 G/s on tables >> 256 MB,
-//                      tools/atomic_ubench.hip) bounds this pass.
-//   win_kernel<true>   same walk; a window whose table entry points at an earlier position sets
-//                      dup[its first byte] = 1.
+//                      no collision list, nothing for the host to resolve.  ONE pass: a window that
+//                      finds an earlier position in its slot marks itself (dup[first byte] = 1), a
+//                      window that replaces a later position (atomicMin) marks the one it displaced,
+//                      so when the kernel ends every occurrence but the earliest is marked.  One
+//                      random atomic per window -- the device's random-atomic rate (~17 G/s on
+//                      tables >> 256 MB, tools/atomic_ubench.hip) bounds the stage.
 //   compact_kernel<false/true>  one wave per document, 64 bytes per step: a code point is gone
 //                      when one of the W code points ending at it starts a marked window; ballots
 //                      + popcounts give every byte its output position (count pass, caller's
@@ -81,7 +82,6 @@ __device__ __forceinline__ bool same_bytes(const uint32_t* tw, uint64_t p, uint6
     return true;
 }
 
-template <bool LINK>
 __global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
     __shared__ WaveLds lds;
     const uint32_t lane = lane_id();
@@ -130,15 +130,14 @@ __global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
                            // mis-sized table from spinning (windows past it are then treated as unique)
                            const uint64_t max_probe = A.tab_size < 65536 ? A.tab_size : 65536;
                            for (uint64_t probe = 0; probe < max_probe; probe++) {
-                               unsigned long long cur = LINK ? A.table[slot] : atomicCAS(&A.table[slot], EMPTY, val);
-                               if (cur == EMPTY || cur == val) return;  // claimed just now / this window is the entry
+                               unsigned long long cur = atomicCAS(&A.table[slot], EMPTY, val);
+                               if (cur == EMPTY) return;  // first occurrence so far; a later, earlier one will mark this window
                                uint64_t q = cur & POS_MASK;
                                if ((cur & ~POS_MASK) == tag && q + L <= A.text_bytes && same_bytes(tw, pos, q, L)) {
-                                   if (LINK) {
-                                       if (q < pos) A.dup[pos] = 1;
-                                   } else if (cur > val) {
-                                       atomicMin(&A.table[slot], val);
-                                   }
+                                   // the slot's content never changes, only its position shrinks.  Whoever loses the
+                                   // comparison is a repeat: this window if the entry is earlier, else the displaced one
+                                   if (cur > val) cur = atomicMin(&A.table[slot], val);
+                                   A.dup[cur > val ? (cur & POS_MASK) : pos] = 1;
                                    return;
                                }
                                slot = slot + 1 == A.tab_size ? 0 : slot + 1;
@@ -255,16 +254,13 @@ extern "C" int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
     HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, ctx->stream));
     uint64_t waves = (uint64_t)ctx->cus * 4 * 8;
     if (waves > n_docs + max_items) waves = n_docs + max_items;
-    for (int pass = 0; pass < 2; pass++) {
-        HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));
-        hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes,
-                           A.seg_bytes, ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items,
-                           (uint32_t*)nullptr, 0);
-        HIP_TRY(hipGetLastError());
-        if (pass == 0) hipLaunchKernelGGL(win_kernel<false>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, A);
-        else hipLaunchKernelGGL(win_kernel<true>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, A);
-        HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes,
+                       A.seg_bytes, ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items,
+                       (uint32_t*)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(win_kernel, dim3((unsigned)waves), dim3(64), 0, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
 
