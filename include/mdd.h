@@ -216,7 +216,10 @@ int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
  *          (offsets range(len - window), SUB:38) whose bytes already occur at a smaller position.
  *          table: workspace u64[tab_size], tab_size >= 2 * number of windows (any size, not only
  *          powers of two; sum over documents of max(0, bytes - window) is a safe window count);
- *          dup: u8[text_bytes].  Both are cleared by the call.
+ *          dup: u8[text_bytes].  When the table for all windows does not fit, call n_parts times
+ *          with part = 0 .. n_parts-1: each call handles the windows whose content key falls into
+ *          that partition (tab_size >= 2 * windows / n_parts, plus slack) and clears the table;
+ *          part 0 clears dup.
  *   count: kept_bytes[d] / kept_cps[d] = bytes / code points of document d that are covered by no
  *          marked window (SUB:58-67).
  *   write: the surviving bytes of every document with keep_doc[d] != 0 (the caller applies
@@ -224,7 +227,7 @@ int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
  *          or beyond out_capacity.
  * 1 <= window <= 128; text 4-byte aligned with MDD_TEXT_PAD spare bytes, text_bytes < 2^40. */
 int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
-                    int window, uint64_t* table, uint64_t tab_size, uint8_t* dup);
+                    int window, int part, int n_parts, uint64_t* table, uint64_t tab_size, uint8_t* dup);
 int mdd_substr_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                      int window, const uint8_t* dup, uint64_t* kept_bytes, uint64_t* kept_cps);
 int mdd_substr_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,

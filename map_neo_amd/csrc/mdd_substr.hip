@@ -42,6 +42,7 @@ struct WinArgs {
     unsigned long long* table;
     uint64_t tab_size;
     uint8_t* dup;
+    uint32_t part, n_parts;  // this launch handles the windows whose key falls into partition `part` of `n_parts`
 };
 
 // 4 bytes at byte address p of the text (any alignment); reads at most 7 bytes past p
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
                            if (lane >= nvalid || sb + L >= len) return;
                            const uint64_t pos = beg + sb;
                            const uint64_t key = window_key(tv, s, L);
+                           if (A.n_parts > 1 && (uint32_t)((key >> 24) % A.n_parts) != A.part) return;
                            const unsigned long long tag = (key & 0xFFFFFFull) << 40;
                            const unsigned long long val = tag | pos;
                            uint64_t slot = __umul64hi(key, A.tab_size);
@@ -219,10 +221,11 @@ unsigned compact_grid(const mdd_ctx* ctx, uint64_t n) {
 }  // namespace
 
 extern "C" int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
-                               int window, uint64_t* table, uint64_t tab_size, uint8_t* dup) {
+                               int window, int part, int n_parts, uint64_t* table, uint64_t tab_size, uint8_t* dup) {
     REQUIRE(ctx, "mdd_substr_mark: ctx is NULL");
     REQUIRE(window >= 1 && window <= 128, "mdd_substr_mark: window=%d outside [1,128]", window);
     REQUIRE(text_bytes < (1ULL << 40), "mdd_substr_mark: text_bytes exceeds 2^40");
+    REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "mdd_substr_mark: part=%d outside [0,%d)", part, n_parts);
     if (n_docs == 0 || text_bytes == 0) return MDD_OK;
     REQUIRE(text && offsets && table && dup, "mdd_substr_mark: NULL buffer");
     REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_mark: text must be 4-byte aligned");
@@ -250,8 +253,10 @@ extern "C" int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
     A.table = reinterpret_cast<unsigned long long*>(table);
     A.tab_size = tab_size;
     A.dup = dup;
+    A.part = (uint32_t)part;
+    A.n_parts = (uint32_t)n_parts;
     HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
-    HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, ctx->stream));
+    if (part == 0) HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, ctx->stream));
     uint64_t waves = (uint64_t)ctx->cus * 4 * 8;
     if (waves > n_docs + max_items) waves = n_docs + max_items;
     HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));

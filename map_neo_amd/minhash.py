@@ -314,9 +314,12 @@ class Engine:
         out_offs = torch.cat([out_offs_all[:-1][docs], out_offs_all[-1:]])
         return out_text, out_offs, docs
 
-    def substr_dedup(self, text: torch.Tensor, offsets: torch.Tensor, window: int = 50, min_length: int = 20):
+    def substr_dedup(self, text: torch.Tensor, offsets: torch.Tensor, window: int = 50, min_length: int = 20,
+                     table_bytes: Optional[int] = None):
         """Exact substring dedup of a packed corpus (SUB:34-95).  Returns (out_text uint8 [padded],
-        out_offsets int64 [n_kept+1], kept document indices int64)."""
+        out_offsets int64 [n_kept+1], kept document indices int64).  The window table (16 bytes per window)
+        is limited to table_bytes (default: 40 % of the free HBM); beyond that the windows are processed in
+        several passes partitioned by content key."""
         n = offsets.numel() - 1
         if n <= 0:
             return (torch.zeros(padded_size(0), dtype=torch.uint8, device=self.device),
@@ -324,10 +327,16 @@ class Engine:
         text_bytes = max(0, text.numel() - TEXT_PAD)
         lens = offsets[1:] - offsets[:-1]
         n_win = int(torch.clamp(lens - window, min=0).sum().item())        # code points <= bytes: an upper bound
-        table = self.empty(max(2, 2 * n_win), torch.int64)
         dup = self.empty(max(1, text_bytes), torch.uint8)
-        _lib.check(self.L.mdd_substr_mark(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(table), table.numel(),
-                                          _ptr(dup)), "mdd_substr_mark")
+        if table_bytes is None:
+            table_bytes = int(torch.cuda.mem_get_info(self.device)[0] * 0.4)
+        n_parts = max(1, -(-(16 * n_win) // max(1, table_bytes)))
+        slots = 2 * n_win if n_parts == 1 else int(2.2 * n_win / n_parts) + 4096      # hash partitions are only nearly equal
+        table = self.empty(max(2, slots), torch.int64)
+        for part in range(n_parts):
+            _lib.check(self.L.mdd_substr_mark(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
+                                              _ptr(table), table.numel(), _ptr(dup)), "mdd_substr_mark")
+        self.last_substr_parts = n_parts
         del table
         kept_b = torch.zeros(n, dtype=torch.int64, device=self.device)
         kept_c = torch.zeros(n, dtype=torch.int64, device=self.device)

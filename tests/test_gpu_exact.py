@@ -126,3 +126,10 @@ def test_exact_substr_dedup_long_and_mixed_documents(engine):
     exp = RX.exact_substr_dedup(rows, 50, 20)
     assert got == exp and small_seg == exp
     assert exact.exact_substr_dedup(engine, rows, 50, 20, fused=False) == exp
+    # window table smaller than the windows need: several passes partitioned by content key
+    from map_neo_amd.minhash import pack_texts
+    buf, offs = pack_texts([t for t, _ in rows])
+    t, o, docs = engine.substr_dedup(engine.to_device(buf), engine.to_device(offs), 50, 20, table_bytes=1 << 20)
+    assert engine.last_substr_parts > 3
+    raw, oo = t.cpu().numpy().tobytes(), o.cpu().numpy()
+    assert [(rows[d][1], raw[int(oo[k]):int(oo[k + 1])].decode("utf8")) for k, d in enumerate(docs.cpu().tolist())] == exp
