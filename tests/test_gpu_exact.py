@@ -133,3 +133,25 @@ def test_exact_substr_dedup_long_and_mixed_documents(engine):
     assert engine.last_substr_parts > 3
     raw, oo = t.cpu().numpy().tobytes(), o.cpu().numpy()
     assert [(rows[d][1], raw[int(oo[k]):int(oo[k + 1])].decode("utf8")) for k, d in enumerate(docs.cpu().tolist())] == exp
+
+
+def test_fused_paths_equal_generic_paths_under_heavy_repetition(engine):
+    """many identical windows / paragraphs inserted concurrently: the one-pass marking (atomicMin names the loser)
+    and the fused compaction must give exactly what the independent generic route gives"""
+    import torch
+    from map_neo_amd.minhash import pack_texts
+    rng = np.random.Generator(np.random.PCG64(17))
+    words = ["w%d" % i for i in range(300)]
+    paras = [" ".join(rng.choice(words, int(rng.integers(5, 40)))) for _ in range(400)]
+    base_docs = ["\n".join(rng.choice(paras, int(rng.integers(1, 10)))) for _ in range(300)]
+    docs = [base_docs[int(i)] for i in rng.integers(0, 300, 20000)]          # ~66 copies of every document
+    for i in range(0, 20000, 7):
+        docs[i] = docs[i] + " tail%d" % i
+    buf, offs = pack_texts(docs)
+    t, o = engine.to_device(buf), engine.to_device(offs)
+    for fn, args in ((exact.exact_substr_dedup_packed, (50, 20)), (exact.paragraph_dedup_packed, (20,))):
+        a = fn(engine, t, o, *args, fused=True)
+        b = fn(engine, t, o, *args, fused=False)
+        assert torch.equal(a[2], b[2]) and torch.equal(a[1], b[1])
+        n = int(a[1][-1].item())
+        assert torch.equal(a[0][:n], b[0][:n]) and n > 0
