@@ -169,6 +169,19 @@ uint64_t ref_signatures(const uint8_t* text, const uint64_t* offsets, uint64_t n
     return tot;
 }
 
+/* same, documents spread over n_threads host threads (OpenMP): the "optimised CPU" line of bench.py's
+ * cpu_baseline; ref_signature keeps no global state */
+uint64_t ref_signatures_mt(const uint8_t* text, const uint64_t* offsets, uint64_t n_docs, int unit, int width, int K,
+                           const uint64_t* a, const uint64_t* b, uint32_t* sig_out, int n_threads) {
+    uint64_t tot = 0;
+    int64_t d;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads) reduction(+ : tot)
+    for (d = 0; d < (int64_t)n_docs; d++)
+        tot += ref_signature(text + offsets[d], offsets[d + 1] - offsets[d], unit, width, K, a, b,
+                             sig_out + (uint64_t)d * (uint64_t)K);
+    return tot;
+}
+
 /* shingle hashes only (for kernel-stage parity tests): writes up to cap hashes, returns count */
 typedef struct { uint32_t* out; uint64_t cap; uint64_t n; } hash_ctx;
 static void hash_collect(void* vctx, const uint8_t* p, uint64_t len) {

@@ -35,6 +35,8 @@ def lib():
         L.ref_make_perms.argtypes = [C.c_uint32, C.c_int, u64p, u64p]
         L.ref_signatures.argtypes = [u8p, u64p, C.c_uint64, C.c_int, C.c_int, C.c_int, u64p, u64p, u32p]
         L.ref_signatures.restype = C.c_uint64
+        L.ref_signatures_mt.argtypes = [u8p, u64p, C.c_uint64, C.c_int, C.c_int, C.c_int, u64p, u64p, u32p, C.c_int]
+        L.ref_signatures_mt.restype = C.c_uint64
         L.ref_shingle_hashes.argtypes = [u8p, C.c_uint64, C.c_int, C.c_int, u32p, C.c_uint64]
         L.ref_shingle_hashes.restype = C.c_uint64
         L.ref_cluster.argtypes = [u32p, C.c_uint64, C.c_int, C.c_int, C.c_int, u32p, u64p]
@@ -65,7 +67,7 @@ UNIT = {'char': 0, 'word': 1}
 
 
 def signatures(text_u8: np.ndarray, offsets: np.ndarray, K: int = 128, width: int = 13,
-               unit: str = 'char', seed: int = 1, perms=None) -> np.ndarray:
+               unit: str = 'char', seed: int = 1, perms=None, threads: int = 1) -> np.ndarray:
     text_u8 = np.ascontiguousarray(text_u8, np.uint8)
     offsets = np.ascontiguousarray(offsets, np.uint64)
     n = offsets.shape[0] - 1
@@ -74,7 +76,10 @@ def signatures(text_u8: np.ndarray, offsets: np.ndarray, K: int = 128, width: in
     b = np.ascontiguousarray(b, np.uint64)
     sig = np.empty((n, K), np.uint32)
     tp = text_u8 if text_u8.size else np.zeros(1, np.uint8)
-    lib().ref_signatures(_p(tp), _p(offsets), n, UNIT[unit], width, K, _p(a), _p(b), _p(sig))
+    if threads > 1:
+        lib().ref_signatures_mt(_p(tp), _p(offsets), n, UNIT[unit], width, K, _p(a), _p(b), _p(sig), threads)
+    else:
+        lib().ref_signatures(_p(tp), _p(offsets), n, UNIT[unit], width, K, _p(a), _p(b), _p(sig))
     return sig
 
 

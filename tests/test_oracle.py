@@ -159,3 +159,10 @@ def test_star_loop_removal_rule():
 def test_normalize_text():
     assert R.normalize_text("  Hello,   World!\n\tFoo-bar  ") == "hello world foobar"
     assert R.normalize_text("ＡＢＣ　ｄｅｆ") == "ａｂｃ ｄｅｆ"      # NFC keeps full-width forms; \s+ matches U+3000
+
+
+def test_c_oracle_multithreaded_equals_single(mini_docs):
+    from map_neo_amd.minhash import pack_texts
+    from oracle import ref_c as RC
+    buf, offs = pack_texts(mini_docs)
+    assert (RC.signatures(buf, offs, threads=4) == RC.signatures(buf, offs)).all()
