@@ -47,6 +47,8 @@ __device__ __forceinline__ void doc_range(const uint64_t* offsets, uint64_t d, u
     beg = beg < end ? beg : end;
 }
 
+// one launch holds at most 2^32 - 1 work-items: thread-per-element launches (256-thread blocks) are checked against this
+constexpr uint64_t MAX_ELEMS_PER_LAUNCH = 0xFFFFFF00ull;
 inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 }  // namespace mddi
 

@@ -64,23 +64,25 @@ __global__ void __launch_bounds__(256) exact_hash_thread_kernel(const uint64_t* 
     key[u] = finish_key(sum, len, key_bits);
 }
 
-// one wave per unit: for long units (documents)
+// one wave per unit: for long units (documents, paragraphs).  Grid-stride: a launch may not exceed 2^32
+// work-items in total, and 64 lanes per unit would pass that at 67 M units.
 __global__ void __launch_bounds__(256) exact_hash_wave_kernel(const uint64_t* t64, uint64_t text_bytes, const uint64_t* ubeg,
                                                               const uint64_t* uend, uint64_t n, int key_bits, uint64_t* key) {
-    uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (u >= n) return;
-    uint32_t lane = lane_id();
-    uint64_t b, len;
-    unit_range(ubeg, uend, u, text_bytes, b, len);
-    uint64_t nch = (len + 7) >> 3, sum = 0;
-    for (uint64_t c = lane; c < nch; c += 64) sum += chunk_term(t64, b, len, c);
+    const uint32_t lane = lane_id();
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < n; u += nw) {
+        uint64_t b, len;
+        unit_range(ubeg, uend, u, text_bytes, b, len);
+        uint64_t nch = (len + 7) >> 3, sum = 0;
+        for (uint64_t c = lane; c < nch; c += 64) sum += chunk_term(t64, b, len, c);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)sum, o, 64);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(sum >> 32), o, 64);
-        sum += ((uint64_t)hi << 32) | lo;
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)sum, o, 64);
+            uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(sum >> 32), o, 64);
+            sum += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 0) key[u] = finish_key(sum, len, key_bits);
     }
-    if (lane == 0) key[u] = finish_key(sum, len, key_bits);
 }
 
 // One 8-byte table entry = (tag << 32 | smallest unit index seen), tag = high half of the key, slot
@@ -157,7 +159,7 @@ extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
                                uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll) {
     REQUIRE(ctx && n_coll, "mdd_exact_group: NULL argument");
     REQUIRE(key_bits >= 1 && key_bits <= 64, "mdd_exact_group: key_bits=%d outside [1,64]", key_bits);
-    REQUIRE(n_units <= 0xFFFFFFFEull, "mdd_exact_group: n_units=%llu exceeds 2^32-2", (unsigned long long)n_units);
+    REQUIRE(n_units <= MAX_ELEMS_PER_LAUNCH, "mdd_exact_group: n_units=%llu exceeds 2^32-256", (unsigned long long)n_units);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(n_coll, 0, sizeof(uint64_t), ctx->stream));
     if (n_units == 0) return MDD_OK;
@@ -167,8 +169,9 @@ extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
             "mdd_exact_group: tab_size=%llu must be a power of two >= 2*n_units", (unsigned long long)tab_size);
     const uint64_t* t64 = reinterpret_cast<const uint64_t*>(text);
     if (avg_unit_bytes >= 256) {
-        REQUIRE(n_units * 64 / 256 + 1 < 0x7FFFFFFFull, "mdd_exact_group: too many units for one launch");
-        hipLaunchKernelGGL(exact_hash_wave_kernel, dim3(grid_for(n_units * 64, 256)), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg,
+        uint64_t blocks = (n_units + 3) / 4;
+        if (blocks > (1u << 22)) blocks = 1u << 22;  // 2^30 work-items: well inside the 2^32 per-launch limit
+        hipLaunchKernelGGL(exact_hash_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg,
                            uend, n_units, key_bits, key_scratch);
     } else {
         hipLaunchKernelGGL(exact_hash_thread_kernel, dim3(grid_for(n_units, 256)), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg,

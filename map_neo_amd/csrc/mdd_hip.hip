@@ -848,6 +848,7 @@ int mdd_band_keys(mdd_ctx* ctx, const uint32_t* sig, uint64_t n_docs, int K, int
     REQUIRE(doc_base + n_docs <= 0xFFFFFFFFull, "mdd_band_keys: global document index exceeds 2^32-1");
     uint64_t n_rec = n_docs * (uint64_t)bands;
     if (n_rec == 0) return MDD_OK;
+    REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_band_keys: %llu records exceed one launch (2^32-256)", (unsigned long long)n_rec);
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(band_keys_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, sig, n_docs, K, bands, rows,
                        doc_base, key_bits, key, meta);
@@ -861,6 +862,7 @@ int mdd_packed_keys(mdd_ctx* ctx, const uint32_t* tuples, const uint64_t* meta, 
     REQUIRE(rows >= 1 && key_bits >= 1 && key_bits <= 64, "mdd_packed_keys: bad rows/key_bits");
     if (n_rec == 0) return MDD_OK;
     REQUIRE(tuples && meta, "mdd_packed_keys: NULL records");
+    REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_packed_keys: n_rec exceeds one launch (2^32-256)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(packed_keys_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, tuples, meta, n_rec, rows,
                        key_bits, key);
@@ -875,6 +877,7 @@ int mdd_route_count(mdd_ctx* ctx, const uint64_t* key, uint64_t n_rec, int world
     HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint64_t) * world, ctx->stream));
     if (n_rec == 0) return MDD_OK;
     REQUIRE(key != nullptr, "mdd_route_count: key is NULL");
+    REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_route_count: n_rec exceeds one launch (2^32-256)");
     hipLaunchKernelGGL(route_count_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, key, n_rec, world,
                        reinterpret_cast<unsigned long long*>(counts));
     HIP_TRY(hipGetLastError());
@@ -888,6 +891,7 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
     REQUIRE(bands >= 1 && rows >= 1 && (int64_t)bands * rows <= K, "mdd_route_pack: bands/rows do not fit K");
     if (n_rec == 0) return MDD_OK;
     REQUIRE(sig && key && meta && tuples_out && meta_out, "mdd_route_pack: NULL records");
+    REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_route_pack: n_rec exceeds one launch (2^32-256)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(route_pack_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, sig, K, bands, rows, key, meta,
                        n_rec, world, reinterpret_cast<unsigned long long*>(send_cursor), tuples_out, meta_out);
@@ -900,7 +904,7 @@ int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, ui
                      uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap, uint64_t* n_edges,
                      uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll, uint64_t* rec_bucket) {
     REQUIRE(ctx && n_edges && n_coll, "mdd_bucket_edges: NULL counter");
-    REQUIRE(n_rec <= 0xFFFFFFFEull, "mdd_bucket_edges: n_rec=%llu exceeds 2^32-2", (unsigned long long)n_rec);
+    REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_bucket_edges: n_rec=%llu exceeds 2^32-256", (unsigned long long)n_rec);
     REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_rec,
             "mdd_bucket_edges: tab_size=%llu must be a power of two >= 2*n_rec", (unsigned long long)tab_size);
     REQUIRE(rec_per_doc >= 1 && rows >= 1, "mdd_bucket_edges: bad tuple addressing");
@@ -927,7 +931,7 @@ int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, ui
 
 int mdd_components_init(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs) {
     REQUIRE(ctx && (labels || n_docs == 0), "mdd_components_init: NULL argument");
-    REQUIRE(n_docs <= 0xFFFFFFFFull, "mdd_components_init: n_docs exceeds 2^32-1");
+    REQUIRE(n_docs <= MAX_ELEMS_PER_LAUNCH, "mdd_components_init: n_docs exceeds 2^32-256");
     if (n_docs == 0) return MDD_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs);
@@ -940,6 +944,7 @@ int mdd_components_union(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs, const 
     REQUIRE(ctx != nullptr, "mdd_components_union: ctx is NULL");
     if (n_edges == 0 || n_docs == 0) return MDD_OK;
     REQUIRE(labels && edge_u && edge_v, "mdd_components_union: NULL buffer");
+    REQUIRE(n_edges <= MAX_ELEMS_PER_LAUNCH && n_docs <= MAX_ELEMS_PER_LAUNCH, "mdd_components_union: more than 2^32-256 edges or documents in one call");
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(uf_union_kernel, dim3(grid_for(n_edges, 256)), dim3(256), 0, ctx->stream, labels, edge_u, edge_v, n_edges,
                        n_docs);
@@ -949,6 +954,7 @@ int mdd_components_union(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs, const 
 
 int mdd_components_finish(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs) {
     REQUIRE(ctx && (labels || n_docs == 0), "mdd_components_finish: NULL argument");
+    REQUIRE(n_docs <= MAX_ELEMS_PER_LAUNCH, "mdd_components_finish: n_docs exceeds one launch (2^32-256)");
     if (n_docs == 0) return MDD_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(uf_flatten_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs);
@@ -963,6 +969,7 @@ int mdd_forest_edges(mdd_ctx* ctx, const uint32_t* labels, uint64_t n_docs, uint
     HIP_TRY(hipMemsetAsync(n_edges, 0, sizeof(uint64_t), ctx->stream));
     if (n_docs == 0) return MDD_OK;
     REQUIRE(labels && (edge_cap == 0 || (edge_u && edge_v)), "mdd_forest_edges: NULL buffer");
+    REQUIRE(n_docs <= MAX_ELEMS_PER_LAUNCH, "mdd_forest_edges: n_docs exceeds one launch (2^32-256)");
     hipLaunchKernelGGL(forest_edges_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs, edge_u,
                        edge_v, edge_cap, reinterpret_cast<unsigned long long*>(n_edges));
     HIP_TRY(hipGetLastError());

@@ -155,3 +155,20 @@ def test_fused_paths_equal_generic_paths_under_heavy_repetition(engine):
         assert torch.equal(a[2], b[2]) and torch.equal(a[1], b[1])
         n = int(a[1][-1].item())
         assert torch.equal(a[0][:n], b[0][:n]) and n > 0
+
+
+def test_exact_group_more_than_2_pow_26_long_units(engine):
+    """70 M overlapping 300-byte units: 64 lanes per unit would exceed the 2^32 work-items of one launch
+    (regression: the wave-per-unit hash kernel is grid-stride)"""
+    import torch
+    n = 70_000_000
+    rng = np.random.Generator(np.random.PCG64(23))
+    buf = np.zeros(4096 + 128, dtype=np.uint8)
+    buf[:4096] = rng.integers(0, 256, 4096)
+    text = engine.to_device(buf)
+    u = torch.arange(n, dtype=torch.int64, device=engine.device)
+    ubeg = (u * 7) % 1000
+    uend = ubeg + 300
+    first = engine.exact_group(text, ubeg, uend)
+    assert engine.last_exact_collisions == 0
+    assert torch.equal(first.to(torch.int64), u % 1000)
