@@ -32,7 +32,7 @@ def main():
     torch.cuda.synchronize()
     print(json.dumps({"docs": a.docs, "text_bytes": total, "gen_s": time.time() - t0}), flush=True)
     for name, fn in (("exact_document_dedup", lambda: exact.exact_document_dedup_packed(eng, text, offs)),
-                     ("paragraph_dedup", lambda: exact.paragraph_dedup_packed(eng, text, offs, 20)),
+                     ("paragraph_dedup", lambda again=(lambda t, o: exact.paragraph_dedup_packed(eng, t, o, 20)): again(text, offs)),
                      ("exact_substr_dedup", lambda: exact.exact_substr_dedup_packed(eng, text, offs, 50, 20))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -47,6 +47,13 @@ def main():
             res["docs_out"] = int(out[2].numel())
         if name == "exact_substr_dedup":
             res["key_partition_passes"] = eng.last_substr_parts
+        if name == "paragraph_dedup":
+            # size-independent property: after the stage no paragraph repeats, so a second pass changes nothing
+            again = fn.__defaults__[0](out[0], out[1])
+            n_b = int(out[1][-1].item())
+            res["idempotent"] = bool(again[2].numel() == out[2].numel() and torch.equal(again[1], out[1])
+                                     and torch.equal(again[0][:n_b], out[0][:n_b]))
+            del again
         print(json.dumps(res), flush=True)
         del out
         torch.cuda.empty_cache()
