@@ -207,6 +207,29 @@ def test_full_size_properties(engine):
     assert (as_u32(sig[torch.from_numpy(sample).to(engine.device)]) == exp).all()
 
 
+def test_offsets_beyond_4_gib(engine):
+    """2.2 M mixed EN/ZH documents = 4.6 GB of text: byte offsets pass 2^32.  Exact copies must get identical
+    signatures and share a component, and a sample of documents from BEHIND the 4 GiB mark matches the oracle."""
+    spec = corpus.CorpusSpec(2_200_000, 2048, lang="mixed", dup_frac=0.15, edit_rate=0.0, seed=77)
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    assert int(offs[-1].item()) > (1 << 32) + (1 << 27)
+    out = dedup_local(engine, text, offs)
+    sig = out["sig"]
+    src = torch.from_numpy(spec.src).to(engine.device)
+    assert torch.equal(sig, sig[src])
+    labels = out["labels"].to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(labels, labels[src])
+    n_comp = int((labels == torch.arange(spec.n_docs, device=engine.device)).sum().item())
+    assert int(out["n_removed"].item()) == spec.n_docs - n_comp
+    o = offs.cpu().numpy()
+    first_high = int(np.searchsorted(o, 1 << 32))
+    sample = np.random.Generator(np.random.PCG64(2)).choice(np.arange(first_high, spec.n_docs), 300, replace=False)
+    docs = [bytes(text[int(o[i]):int(o[i + 1])].cpu().numpy()) for i in sample]
+    buf, so = pack_texts(docs)
+    exp = RC.signatures(buf, so, 128)
+    assert (as_u32(sig[torch.from_numpy(sample).to(engine.device)]) == exp).all()
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_routed_packed_path(engine, mini_docs, mini_expected, world):
     """multi-GPU data path on one GPU: route band records to `world` owners (mdd_route_count /
