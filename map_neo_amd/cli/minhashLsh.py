@@ -87,6 +87,39 @@ def _write_file(task):
     return kept
 
 
+def removed_doc_ids(eng, sig, cand_ids, bands: int, rows: int):
+    """EN:133-147 on signatures in HBM: (set of doc_ids to remove, component label per candidate row)."""
+    from ..dedup import cluster_local
+    from ..minhash import as_u32
+    n = len(cand_ids)
+    out = cluster_local(eng, sig, bands, rows)
+    labels = as_u32(out["labels"])
+    # rows sharing one doc_id are ONE node of the reference's graph (its edges carry doc_ids)
+    first_of, extra = {}, []
+    for k, d in enumerate(cand_ids):
+        j = first_of.setdefault(d, k)
+        if j != k:
+            extra.append((k, j))
+    if extra:
+        lab = eng.components_init(n)
+        eng.components_union(lab, out["edge_u"], out["edge_v"])
+        e = np.asarray(extra, dtype=np.uint32)
+        eng.components_union(lab, eng.to_device(np.ascontiguousarray(e[:, 0])),
+                             eng.to_device(np.ascontiguousarray(e[:, 1])))
+        eng.components_finish(lab)
+        labels = as_u32(lab)
+    # survivor of a component = smallest doc_id (EN:145), whatever its position in the input
+    members = np.flatnonzero(labels != np.arange(n, dtype=np.uint32))
+    comp_min = {}
+    for k in set(labels[members].tolist()) | set(members.tolist()):
+        l = int(labels[k])
+        d = cand_ids[k]
+        if l not in comp_min or d < comp_min[l]:
+            comp_min[l] = d
+    remove_ids = {cand_ids[k] for k in comp_min_members(labels, members) if cand_ids[k] != comp_min[int(labels[k])]}
+    return remove_ids, labels
+
+
 def minhashLsh(args) -> dict:
     from .. import hostio
     files = hostio.list_files(args.input_dir)
@@ -98,7 +131,6 @@ def minhashLsh(args) -> dict:
 
         import torch
 
-        from ..dedup import cluster_local
         from ..minhash import Engine, as_u32, padded_size
         eng = Engine(args.device)
         sigs, cand_ids, n_rows = [], [], 0
@@ -113,31 +145,7 @@ def minhashLsh(args) -> dict:
         t1 = time.time()
         n = len(cand_ids)
         sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
-        out = cluster_local(eng, sig, args.bands, args.rows)
-        labels = as_u32(out["labels"])
-        # rows sharing one doc_id are ONE node of the reference's graph (its edges carry doc_ids)
-        first_of, extra = {}, []
-        for k, d in enumerate(cand_ids):
-            j = first_of.setdefault(d, k)
-            if j != k:
-                extra.append((k, j))
-        if extra:
-            lab = eng.components_init(n)
-            eng.components_union(lab, out["edge_u"], out["edge_v"])
-            e = np.asarray(extra, dtype=np.uint32)
-            eng.components_union(lab, eng.to_device(np.ascontiguousarray(e[:, 0])),
-                                 eng.to_device(np.ascontiguousarray(e[:, 1])))
-            eng.components_finish(lab)
-            labels = as_u32(lab)
-        # survivor of a component = smallest doc_id (EN:145), whatever its position in the input
-        members = np.flatnonzero(labels != np.arange(n, dtype=np.uint32))
-        comp_min = {}
-        for k in set(labels[members].tolist()) | set(members.tolist()):
-            l = int(labels[k])
-            d = cand_ids[k]
-            if l not in comp_min or d < comp_min[l]:
-                comp_min[l] = d
-        remove_ids = {cand_ids[k] for k in comp_min_members(labels, members) if cand_ids[k] != comp_min[int(labels[k])]}
+        remove_ids, labels = removed_doc_ids(eng, sig, cand_ids, args.bands, args.rows)
         t2 = time.time()
 
         os.makedirs(args.inter_dir, exist_ok=True)

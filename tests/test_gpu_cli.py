@@ -308,3 +308,33 @@ def test_stage_entry_point_distributed_one_rank(tmp_path, mini_docs):
     assert outs["single"] == outs["dist"]
     lab = R.dedup(mini_docs)["labels"]
     assert len(outs["dist"]["removed_ids.txt"].split()) == int((lab != np.arange(n)).sum())
+
+
+def test_en_pipeline_equals_the_four_commands_chained(tmp_path):
+    """one process with the corpus kept in HBM == exact_document_deduplication -> minhashLsh -> paragraph ->
+    exact_substr_dedup chained through gzip JSON files"""
+    from map_neo_amd.cli import en_dedup_pipeline, exact_document_deduplication, exact_substr_dedup, paragraph
+    rng = np.random.Generator(np.random.PCG64(41))
+    words = ["Alpha", "beta,", "GAMMA", "delta.", "epsilon", "zeta!", "naïve", "数据", "eta", "theta", "iota", "kappa"]
+    paras = [" ".join(rng.choice(words, int(rng.integers(8, 40)))) for _ in range(60)]
+    docs = ["\n".join(rng.choice(paras, int(rng.integers(2, 9)))) for _ in range(200)]
+    docs += [docs[int(i)] for i in rng.integers(0, 200, 40)]                                  # exact copies
+    docs += [docs[int(i)].replace("beta,", "BETA", 1) + " x" for i in rng.integers(0, 200, 40)]  # near copies
+    ids = [f"d{int(i):04d}" for i in rng.permutation(len(docs))]
+    rows = [{"doc_id": i, "raw_content": t, "url": f"http://x/{k}"} for k, (i, t) in enumerate(zip(ids, docs))]
+    rows[7]["raw_content"] = None
+    inp = tmp_path / "in"
+    inp.mkdir()
+    _write_jsonl(inp / "a.json", rows[:150])
+    _write_jsonl(inp / "b.json.gz", rows[150:], gz=True)
+    w = ["--workers", "2"]
+    exact_document_deduplication.main(["--input_dir", str(inp), "--output_dir", str(tmp_path / "s1")] + w)
+    minhashLsh.main(["--input_dir", str(tmp_path / "s1"), "--inter_dir", str(tmp_path / "m"), "--output_dir", str(tmp_path / "s2")] + w)
+    paragraph.main(["--input_dir", str(tmp_path / "s2"), "--output_dir", str(tmp_path / "s3")] + w)
+    exact_substr_dedup.main(["--input_dir", str(tmp_path / "s3"), "--output_dir", str(tmp_path / "s4")] + w)
+    chained = _read_parts(tmp_path / "s4")
+    st = en_dedup_pipeline.run(en_dedup_pipeline.build_parser().parse_args(["--input_dir", str(inp), "--output_dir", str(tmp_path / "p")] + w))
+    fused = _read_parts(tmp_path / "p")
+    assert fused == chained and 0 < len(fused) < len(rows)
+    assert st["after_exact_document"] < st["rows_with_content"] and st["after_minhash"] < st["after_exact_document"]
+    assert st["after_exact_substring"] == len(fused)
