@@ -85,9 +85,12 @@ def _write_part(task):
     return len(ids)
 
 
-def write_docs(output_dir: str, ids, text, offs, workers: int, docs_per_part: int = 100_000) -> int:
-    """gzip JSON lines {"doc_id", "raw_content"} (the two columns PAR:27-28 / SUB:92 keep), one part per 100k documents"""
+def write_docs(output_dir: str, ids, text, offs, workers: int, docs_per_part: int = 0) -> int:
+    """gzip JSON lines {"doc_id", "raw_content"} (the two columns PAR:27-28 / SUB:92 keep); the part size is chosen
+    so that every worker gets several parts (gzip is the slow step), at most 100k documents each"""
     os.makedirs(output_dir, exist_ok=True)
+    if docs_per_part <= 0:
+        docs_per_part = min(100_000, max(1000, -(-len(ids) // (4 * max(1, workers)))))
     raw, o = text.cpu().numpy(), offs.cpu().numpy()
     tasks = []
     for p, k0 in enumerate(range(0, len(ids), docs_per_part)):

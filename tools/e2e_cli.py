@@ -17,6 +17,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
     shards = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    mode = sys.argv[4] if len(sys.argv) > 4 else "minhash"      # "minhash": the EN drop-in; "pipeline": en_dedup_pipeline
     from map_neo_amd import corpus
     spec = corpus.CorpusSpec(n, 2048, seed=7, lang="en")
     text, offs = corpus.generate(spec)
@@ -32,6 +33,17 @@ def main():
             for i in range(s * per, min(n, (s + 1) * per)):
                 f.write(json.dumps({"doc_id": f"shard/{s:04d}/{i:09d}", "raw_content": tb[o[i]:o[i + 1]].decode(), "url": "x"}) + "\n")
     t_write = time.time() - t0
+    if mode == "pipeline":
+        from map_neo_amd.cli import en_dedup_pipeline as P
+        t0 = time.time()
+        stats = P.run(P.build_parser().parse_args(["--input_dir", inp, "--output_dir", os.path.join(root, "out"),
+                                                   "--workers", str(workers)]))
+        wall = time.time() - t0
+        stats.update({"mode": mode, "docs": n, "text_bytes": int(o[-1]), "wall_s": wall, "docs_per_s": n / wall, "shards": shards,
+                      "workers": workers, "make_input_s": t_write})
+        print(json.dumps(stats))
+        shutil.rmtree(root, ignore_errors=True)
+        return
     from map_neo_amd.cli import minhashLsh
     t0 = time.time()
     stats = minhashLsh.minhashLsh(minhashLsh.build_parser().parse_args(
