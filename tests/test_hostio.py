@@ -179,3 +179,20 @@ def test_parquet_shard_reader_matches_row_path(tmp_path):
     # absent column / non-string column: nothing to hash
     assert len(hostio.read_parquet_shard(path, "missing", "doc_id")["cand"]) == 0
     assert len(hostio.read_parquet_shard(path, "n", "doc_id")["cand"]) == 0
+
+
+def test_parquet_shard_reader_leaves_invalid_utf8_rows_unhashed(tmp_path):
+    """rows whose bytes are not utf-8 (a lone surrogate's CESU bytes, stray 0xFF) cannot be a Python str in the
+    reference (ZH-1:52-54 skips such lines): they are never hashed, hence always kept"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from map_neo_amd import hostio
+    vals = [b"good one", b"bad \xff\xfe bytes", b"", b"caf\xc3\xa9", b"lone \xed\xa0\x80 surrogate"]
+    offs = np.zeros(len(vals) + 1, np.int32)
+    offs[1:] = np.cumsum([len(v) for v in vals])
+    arr = pa.Array.from_buffers(pa.string(), len(vals), [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(b"".join(vals))])
+    path = str(tmp_path / "x.parquet")
+    pq.write_table(pa.table({"doc_id": [f"d{i}" for i in range(5)], "raw_content": arr}), path)
+    r = hostio.read_parquet_shard(path, "raw_content", "doc_id")
+    assert r["cand"].tolist() == [0, 2, 3] and r["ids"] == [f"d{i}" for i in range(5)]
+    assert bytes(r["text"]) == b"good onecaf\xc3\xa9" and r["offsets"].tolist() == [0, 8, 8, 13]
