@@ -306,6 +306,20 @@ def main():
         except Exception as e:  # pinned allocation can fail on small hosts: the figures are optional
             print(f"[bench] PCIe figures skipped: {e}", file=sys.stderr)
             h2d_ms = None
+    # achievable HBM bandwidth on this device (calibrate with a device copy): read + write of the text
+    hbm_copy_gbps = None
+    if rank == 0:
+        dst = torch.empty_like(text)
+        dst.copy_(text)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(text)
+        e1.record()
+        torch.cuda.synchronize()
+        hbm_copy_gbps = 2 * text.numel() * 5 / (e0.elapsed_time(e1) * 1e6)
+        del dst
     lens = offsets[1:] - offsets[:-1]
     n_shingles = int(torch.clamp(lens - (WIDTH - 1), min=0).sum().item())      # ASCII corpus: code points == bytes
 
@@ -398,6 +412,7 @@ def main():
                                  "achieved_gb_per_s": v * n_local / (res["stage_ms_per_step_rank0"][k] * 1e6),
                                  "frac_of_8TBps": v * n_local / (res["stage_ms_per_step_rank0"][k] * 1e6) / 8000.0}
                              for k, v in hbm_alg.items() if res["stage_ms_per_step_rank0"].get(k)}
+        res["hbm_copy_gb_per_s_measured"] = hbm_copy_gbps
         if cpu is not None:
             res["cpu_baseline"] = cpu
         if args.stages and world == 1:
