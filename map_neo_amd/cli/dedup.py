@@ -120,7 +120,13 @@ def run(args, engine_factory=None) -> dict:
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.time()
-    pool = mp.get_context("fork").Pool(max(1, args.workers // world))      # forked before this process touches the GPU
+    n_workers = max(1, args.workers // world)
+    if files and all(f.lower().endswith((".parquet", ".pq")) for f in files):
+        # Arrow decodes without the GIL and hands its buffers over without a copy: threads, not processes
+        from multiprocessing.pool import ThreadPool
+        pool = ThreadPool(n_workers)
+    else:
+        pool = mp.get_context("fork").Pool(n_workers)                      # forked before this process touches the GPU
     try:
         parsed = pool.imap(_parse_shard, [(p, args.id_field, args.content_field, args.normalize) for p in files])
         import torch

@@ -33,6 +33,29 @@ def main():
             for i in range(s * per, min(n, (s + 1) * per)):
                 f.write(json.dumps({"doc_id": f"shard/{s:04d}/{i:09d}", "raw_content": tb[o[i]:o[i + 1]].decode(), "url": "x"}) + "\n")
     t_write = time.time() - t0
+    if mode == "parquet":
+        # the stage entry point on Parquet shards: Arrow buffers -> HBM, EN normalisation on the device
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+        from map_neo_amd.cli import dedup as stage
+        pin = os.path.join(root, "pq")
+        os.makedirs(pin)
+        t0 = time.time()
+        for s_ in range(shards):
+            lo, hi = s_ * per, min(n, (s_ + 1) * per)
+            pq.write_table(pa.table({"doc_id": [f"shard/{s_:04d}/{i:09d}" for i in range(lo, hi)],
+                                     "raw_content": [tb[o[i]:o[i + 1]].decode() for i in range(lo, hi)]}),
+                           os.path.join(pin, f"shard-{s_:04d}.parquet"))
+        t_pq = time.time() - t0
+        t0 = time.time()
+        stats = stage.run(stage.build_parser().parse_args(["--input_dir", pin, "--output_dir", os.path.join(root, "out"),
+                                                           "--normalize", "en", "--workers", str(workers)]))
+        wall = time.time() - t0
+        stats.update({"mode": mode, "docs": n, "text_bytes": int(o[-1]), "wall_s": wall, "docs_per_s": n / wall, "shards": shards,
+                      "workers": workers, "make_parquet_s": t_pq})
+        print(json.dumps(stats))
+        shutil.rmtree(root, ignore_errors=True)
+        return
     if mode == "pipeline":
         from map_neo_amd.cli import en_dedup_pipeline as P
         t0 = time.time()
