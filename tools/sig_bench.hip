@@ -47,7 +47,12 @@ int main(int argc, char** argv) {
     for (uint64_t d = 0; d < n; d++) {
         uint64_t len = offs[d + 1] - offs[d];
         uint64_t cp = lang == 0 ? len : len / 3;
-        if (cp >= 13) nsh += cp - 12;
+        if (unit == 1) {  // word unit: tokens = maximal runs of non-space bytes
+            cp = 0;
+            for (uint64_t i = offs[d]; i < offs[d + 1]; i++)
+                if (text[i] != ' ' && (i == offs[d] || text[i - 1] == ' ')) cp++;
+        }
+        if (cp >= (uint64_t)width) nsh += cp - (uint64_t)width + 1;
     }
     std::vector<uint64_t> a(K), b(K);
     mdd_make_perms(1, K, a.data(), b.data());
