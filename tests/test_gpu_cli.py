@@ -338,3 +338,33 @@ def test_en_pipeline_equals_the_four_commands_chained(tmp_path):
     assert fused == chained and 0 < len(fused) < len(rows)
     assert st["after_exact_document"] < st["rows_with_content"] and st["after_minhash"] < st["after_exact_document"]
     assert st["after_exact_substring"] == len(fused)
+
+
+def test_full_text_dedup_cli(tmp_path):
+    """ZH full-text dedup: first line of every distinct `text` survives byte for byte, parts of --batch_size lines"""
+    from map_neo_amd.cli import full_text_dedup as cli
+    rng = np.random.Generator(np.random.PCG64(51))
+    texts = ["文档%d 内容 %s" % (i, "甲乙丙丁"[i % 4] * (i % 7)) for i in range(120)]
+    rows = [{"text": texts[int(i)], "meta": int(k)} for k, i in enumerate(rng.integers(0, 120, 400))]
+    inp = tmp_path / "in"
+    inp.mkdir()
+    lines = [json.dumps(r, ensure_ascii=bool(k % 2)) + "\n" for k, r in enumerate(rows)]
+    lines[17] = "not json\n"
+    lines[33] = json.dumps({"other": 1}) + "\n"
+    with open(inp / "b.jsonl", "w", encoding="utf8") as f:
+        f.writelines(lines[250:])
+    with open(inp / "a.jsonl", "w", encoding="utf8") as f:
+        f.writelines(lines[:250])
+    st = cli.run(cli.build_parser().parse_args(["--input_dir", str(inp), "--output_dir", str(tmp_path / "o"), "--batch_size", "50"]))
+    seen, exp = set(), []
+    for k, line in enumerate(lines):                       # a.jsonl (lines[:250]) sorts before b.jsonl
+        if k in (17, 33):
+            continue
+        t = rows[k]["text"]
+        if t not in seen:
+            seen.add(t)
+            exp.append(line)
+    parts = sorted(os.listdir(tmp_path / "o"), key=lambda n: int(n.split("_")[1].split(".")[0]))
+    got = [l for p in parts for l in open(tmp_path / "o" / p, encoding="utf8")]
+    assert got == exp and st["n_kept"] == len(exp) and st["n_without_content"] == 1
+    assert parts[:-1] == [f"part_{i}.jsonl" for i in range(len(parts) - 1)] and parts[-1] == f"part_{len(parts) - 1}"
