@@ -127,21 +127,22 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
  *   PACKED layout: tuple_base = tuples, rec_per_doc = 1, doc_stride = rows, band_stride = 0
  * Workspace (caller-allocated): table u64[tab_size], tab_size a power of two >= 2*n_rec.
  * The call clears it.
- * Output: for every record that is not the representative (lowest record index) of its
- * bucket one edge (doc, doc_of_representative), appended to edge_u/edge_v (u32 global doc
- * indices; order of edges unspecified, set deterministic).  *n_edges (device u64) counts
- * them; at most edge_cap are written (n_rec always suffices).
- * Records whose surrogate key equals another bucket's but whose tuple differs (surrogate
- * collisions) are NOT linked here: their record indices are appended to coll_idx (u64,
- * capacity coll_cap) and counted in *n_coll (device u64); the caller resolves them exactly
- * (map_neo_amd.dedup does, on the host).  rec_bucket (optional, may be NULL): u64[n_rec],
- * record index of the representative of the record's surrogate slot (bucket id for tests). */
+ * Output: every record except the lowest-indexed one of its bucket emits one edge
+ * (its document, the document of a lower-indexed record of the same bucket), appended to
+ * edge_u/edge_v (u32 global doc indices; which lower record, and the order of the edges, depend
+ * on scheduling -- the connected components do not).  Edges between records of one document
+ * are dropped.  *n_edges (device u64) counts them; at most edge_cap are written (n_rec always
+ * suffices).
+ * The 64-bit surrogate key only picks the slot and a 32-bit tag; a tag match is confirmed on the
+ * exact (band, tuple), so buckets are exact and nothing is left to the caller.  *n_coll (device
+ * u64) counts the tag matches that turned out to be different tuples (statistics).
+ * rec_bucket (optional, may be NULL): u64[n_rec], lowest record index of the record's bucket
+ * (costs a second pass; used by tests). */
 int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, uint64_t n_rec,
                      const uint32_t* tuple_base, uint64_t rec_per_doc, uint64_t doc_stride,
-                     uint64_t band_stride, int rows, uint64_t* table,
-                     uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap,
-                     uint64_t* n_edges, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll,
-                     uint64_t* rec_bucket);
+                     uint64_t band_stride, int rows, uint64_t* table, uint64_t tab_size,
+                     uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap, uint64_t* n_edges,
+                     uint64_t* n_coll, uint64_t* rec_bucket);
 
 /* Connected components.  Replaces the large-star/small-star loop (EN:82-115, EN:138-144)
  * and networkit ConnectedComponents (ZH-3:11-27): union-find over n_docs global indices;

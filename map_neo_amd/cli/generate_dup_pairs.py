@@ -24,7 +24,7 @@ def build_parser():
 
 def process_partition(args):
     from .. import hostio
-    from ..minhash import Engine, as_u32, as_u64, resolve_collisions
+    from ..minhash import Engine, as_u64
     eng = Engine(args.device)
     os.makedirs(args.output_dir, exist_ok=True)
     for band_name in sorted(os.listdir(args.input_dir)):
@@ -51,14 +51,11 @@ def process_partition(args):
             meta = np.arange(n, dtype=np.uint64)                 # one band per call: band field 0
             t_d, m_d = eng.to_device(np.ascontiguousarray(tup.reshape(-1))), eng.to_device(meta)
             k_d = eng.packed_keys(t_d, m_d, rows)
-            eu, ev, coll, _ = eng.bucket_edges(k_d, m_d, t_d, 1, rows, 0, rows)
-            eu, ev = as_u32(eu), as_u32(ev)
-            if coll.size:
-                xu, xv = resolve_collisions(coll, meta, lambda i: tup[i].tobytes())
-                eu, ev = np.concatenate([eu, xu]), np.concatenate([ev, xv])
-            order = np.argsort(eu, kind="stable")                # emit in document order like the sequential scan
-            for u, v in zip(eu[order].tolist(), ev[order].tolist()):
-                fw.write(f"{ids[u]} :: {ids[v]}\n")
+            # ZH-2:30-37 writes "doc :: first doc seen with this key": the bucket's lowest record (rec_bucket)
+            _, _, _, rb = eng.bucket_edges(k_d, m_d, t_d, 1, rows, 0, rows, want_buckets=True)
+            first = as_u64(rb).astype(np.int64)
+            for u in np.flatnonzero(first != np.arange(n)).tolist():   # in document order like the sequential scan
+                fw.write(f"{ids[u]} :: {ids[int(first[u])]}\n")
 
 
 def main(argv=None):

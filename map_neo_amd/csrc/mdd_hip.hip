@@ -494,29 +494,15 @@ struct TupleAddr {
     }
 };
 
-// One 8-byte table entry = (high half of the surrogate key << 32 | lowest record index seen): a single random
-// atomic per record (the claim) -- every device atomic is a whole memory transaction, so this halves the
-// stage's traffic against a key array + a representative array.  A same-tag entry of another key is just one
-// more surrogate collision: the tuple comparison in bucket_link_kernel catches it.
+// Bucketing in ONE pass over the records.  One 8-byte table entry = (high half of the surrogate key << 32 | lowest
+// record index seen so far).  A record claims its slot with one atomicCAS; when it meets an entry with its tag it
+// compares the EXACT (band, r-tuple) with that record's: different -> just another occupant, keep probing (so the
+// table is exact and nothing is left for the host); equal -> same bucket: the later record of the two emits the
+// edge (its document, the earlier one's document) -- if this record is the earlier one it takes the slot with
+// atomicMin, whose return value names the record it displaced.  Every record of a bucket except its lowest thus
+// links to a lower record of the same bucket: a tree per bucket, which is all the union-find needs.  Every device
+// atomic is a whole memory transaction, so one atomic per record (and no second lookup pass) is the floor here.
 constexpr unsigned long long TAB_EMPTY = ~0ULL;
-
-__global__ void __launch_bounds__(256) bucket_insert_kernel(const uint64_t* key, uint64_t n_rec, unsigned long long* tab,
-                                                            uint64_t tab_mask) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rec) return;
-    unsigned long long k = key[i];
-    unsigned long long val = (k & 0xFFFFFFFF00000000ULL) | (uint32_t)i;
-    uint64_t slot = mix64(k) & tab_mask;
-    for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: table is never full (size >= 2*n_rec)
-        unsigned long long cur = atomicCAS(&tab[slot], TAB_EMPTY, val);
-        if (cur == TAB_EMPTY) return;
-        if ((cur >> 32) == (val >> 32)) {
-            if (cur > val) atomicMin(&tab[slot], val);
-            return;
-        }
-        slot = (slot + 1) & tab_mask;
-    }
-}
 
 __device__ __forceinline__ void append_edge(uint32_t u, uint32_t v, bool have, uint32_t* edge_u, uint32_t* edge_v,
                                             uint64_t cap, unsigned long long* n_edges) {
@@ -538,44 +524,67 @@ __device__ __forceinline__ void append_edge(uint32_t u, uint32_t v, bool have, u
     }
 }
 
-__global__ void __launch_bounds__(256) bucket_link_kernel(const uint64_t* key, const uint64_t* meta, uint64_t n_rec, TupleAddr ta,
-                                                          const unsigned long long* tab, uint64_t tab_mask, uint32_t* edge_u, uint32_t* edge_v,
-                                                          uint64_t edge_cap, unsigned long long* n_edges, uint64_t* coll_idx,
-                                                          uint64_t coll_cap, unsigned long long* n_coll, uint64_t* rec_bucket) {
+__device__ __forceinline__ bool same_bucket(const TupleAddr& ta, const uint64_t* meta, uint64_t i, uint64_t mi, uint64_t q) {
+    const uint32_t* x = ta.at(i);
+    const uint32_t* y = ta.at(q);
+    bool same = (mi >> 56) == (meta[q] >> 56);
+    for (int r = 0; r < ta.rows; r++) same &= x[r] == y[r];
+    return same;
+}
+
+__global__ void __launch_bounds__(256) bucket_insert_kernel(const uint64_t* key, const uint64_t* meta, uint64_t n_rec, TupleAddr ta,
+                                                            unsigned long long* tab, uint64_t tab_mask, uint32_t* edge_u,
+                                                            uint32_t* edge_v, uint64_t edge_cap, unsigned long long* n_edges,
+                                                            unsigned long long* n_coll) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool have = false;
     uint32_t eu = 0, ev = 0;
     if (i < n_rec) {
         unsigned long long k = key[i];
+        unsigned long long val = (k & 0xFFFFFFFF00000000ULL) | (uint32_t)i;
+        uint64_t mi = meta[i];
         uint64_t slot = mix64(k) & tab_mask;
-        uint32_t rep = (uint32_t)i;
-        for (uint64_t probe = 0; probe <= tab_mask; probe++) {
-            unsigned long long cur = tab[slot];
-            if (cur == TAB_EMPTY) break;  // cannot happen after insert; defensive
-            if ((cur >> 32) == (k >> 32)) {
-                rep = (uint32_t)cur;
-                break;
+        for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: table is never full (size >= 2*n_rec)
+            unsigned long long cur = atomicCAS(&tab[slot], TAB_EMPTY, val);
+            if (cur == TAB_EMPTY) break;  // lowest record of its bucket so far
+            if ((cur >> 32) == (val >> 32)) {
+                if (same_bucket(ta, meta, i, mi, (uint32_t)cur)) {
+                    // the slot's bucket never changes, only its record index shrinks
+                    if (cur > val) cur = atomicMin(&tab[slot], val);
+                    uint32_t other = (uint32_t)cur;
+                    uint32_t d_me = (uint32_t)mi, d_other = (uint32_t)meta[other];
+                    eu = cur > val ? d_other : d_me;  // the later record links to the earlier one
+                    ev = cur > val ? d_me : d_other;
+                    have = eu != ev;
+                    break;
+                }
+                atomicAdd(n_coll, 1ULL);  // same 32-bit tag, different (band, tuple): statistics only
             }
             slot = (slot + 1) & tab_mask;
         }
-        if (rec_bucket) rec_bucket[i] = rep;
-        if (rep != (uint32_t)i) {
-            const uint32_t* x = ta.at(i);
-            const uint32_t* y = ta.at(rep);
-            uint64_t mi = meta[i], mr = meta[rep];
-            bool same = (mi >> 56) == (mr >> 56);
-            for (int r = 0; r < ta.rows; r++) same &= x[r] == y[r];
-            if (same) {
-                eu = (uint32_t)mi;
-                ev = (uint32_t)mr;
-                have = eu != ev;
-            } else {
-                unsigned long long o = atomicAdd(n_coll, 1ULL);
-                if (o < coll_cap) coll_idx[o] = i;
-            }
-        }
     }
     append_edge(eu, ev, have, edge_u, edge_v, edge_cap, n_edges);
+}
+
+// Optional second pass (tests): rec_bucket[i] = lowest record index of record i's bucket
+__global__ void __launch_bounds__(256) bucket_ids_kernel(const uint64_t* key, const uint64_t* meta, uint64_t n_rec, TupleAddr ta,
+                                                         const unsigned long long* tab, uint64_t tab_mask, uint64_t* rec_bucket) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    unsigned long long k = key[i];
+    uint64_t mi = meta[i];
+    uint64_t slot = mix64(k) & tab_mask;
+    uint64_t rep = i;
+    for (uint64_t probe = 0; probe <= tab_mask; probe++) {
+        unsigned long long cur = tab[slot];
+        if (cur == TAB_EMPTY) break;  // cannot happen after the insert pass; defensive
+        if ((cur >> 32) == (k >> 32) && ((uint32_t)cur == (uint32_t)i || same_bucket(ta, meta, i, mi, (uint32_t)cur))) {
+            rep = (uint32_t)cur;
+            break;
+        }
+        slot = (slot + 1) & tab_mask;
+    }
+    rec_bucket[i] = rep;
 }
 
 __global__ void __launch_bounds__(256) iota_kernel(uint32_t* p, uint64_t n) {
@@ -902,7 +911,7 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
 int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, uint64_t n_rec, const uint32_t* tuple_base,
                      uint64_t rec_per_doc, uint64_t doc_stride, uint64_t band_stride, int rows, uint64_t* table,
                      uint64_t tab_size, uint32_t* edge_u, uint32_t* edge_v, uint64_t edge_cap, uint64_t* n_edges,
-                     uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll, uint64_t* rec_bucket) {
+                     uint64_t* n_coll, uint64_t* rec_bucket) {
     REQUIRE(ctx && n_edges && n_coll, "mdd_bucket_edges: NULL counter");
     REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_bucket_edges: n_rec=%llu exceeds 2^32-256", (unsigned long long)n_rec);
     REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_rec,
@@ -912,20 +921,19 @@ int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, ui
     HIP_TRY(hipMemsetAsync(n_edges, 0, sizeof(uint64_t), ctx->stream));
     HIP_TRY(hipMemsetAsync(n_coll, 0, sizeof(uint64_t), ctx->stream));
     if (n_rec == 0) return MDD_OK;
-    REQUIRE(key && meta && tuple_base && table && (edge_cap == 0 || (edge_u && edge_v)) &&
-                (coll_cap == 0 || coll_idx),
-            "mdd_bucket_edges: NULL buffer");
+    REQUIRE(key && meta && tuple_base && table && (edge_cap == 0 || (edge_u && edge_v)), "mdd_bucket_edges: NULL buffer");
     HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
     unsigned g = grid_for(n_rec, 256);
-    hipLaunchKernelGGL(bucket_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key, n_rec,
-                       reinterpret_cast<unsigned long long*>(table), tab_size - 1);
-    HIP_TRY(hipGetLastError());
     TupleAddr ta{tuple_base, rec_per_doc, doc_stride, band_stride, rows};
-    hipLaunchKernelGGL(bucket_link_kernel, dim3(g), dim3(256), 0, ctx->stream, key, meta, n_rec, ta,
-                       reinterpret_cast<const unsigned long long*>(table), tab_size - 1, edge_u, edge_v, edge_cap,
-                       reinterpret_cast<unsigned long long*>(n_edges), coll_idx, coll_cap,
-                       reinterpret_cast<unsigned long long*>(n_coll), rec_bucket);
+    hipLaunchKernelGGL(bucket_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key, meta, n_rec, ta,
+                       reinterpret_cast<unsigned long long*>(table), tab_size - 1, edge_u, edge_v, edge_cap,
+                       reinterpret_cast<unsigned long long*>(n_edges), reinterpret_cast<unsigned long long*>(n_coll));
     HIP_TRY(hipGetLastError());
+    if (rec_bucket) {
+        hipLaunchKernelGGL(bucket_ids_kernel, dim3(g), dim3(256), 0, ctx->stream, key, meta, n_rec, ta,
+                           reinterpret_cast<const unsigned long long*>(table), tab_size - 1, rec_bucket);
+        HIP_TRY(hipGetLastError());
+    }
     return MDD_OK;
 }
 

@@ -20,21 +20,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .minhash import BANDS, NUM_PERM, ROWS, SEED, WIDTH, as_u32, as_u64, resolve_collisions
-
-
-def _resolve_sig_layout(be, coll_idx, sig, meta, bands, rows):
-    if coll_idx.size == 0:
-        return None
-    meta_h = as_u64(meta)
-    K = sig.shape[1]
-    sig_h = as_u32(sig)
-
-    def tuple_of(i):
-        d, j = divmod(i, bands)
-        return sig_h[d, j * rows:(j + 1) * rows].tobytes()
-
-    return resolve_collisions(coll_idx, meta_h, tuple_of)
+from .minhash import BANDS, NUM_PERM, ROWS, SEED, WIDTH
 
 
 class StageTimer:
@@ -64,20 +50,15 @@ def cluster_local(be, sig: torch.Tensor, bands: int = BANDS, rows: int = ROWS, k
     mark = timer.mark if timer is not None else (lambda name: None)
     key, meta = be.band_keys(sig, bands, rows, 0, key_bits)
     mark("band_keys")
-    eu, ev, coll_idx, rb = be.bucket_edges(key, meta, sig, bands, num_perm, rows, rows, want_buckets)
+    eu, ev, n_coll, rb = be.bucket_edges(key, meta, sig, bands, num_perm, rows, rows, want_buckets)
     mark("bucket_edges")
     labels = be.components_init(n)
     be.components_union(labels, eu, ev)
-    extra = _resolve_sig_layout(be, coll_idx, sig, meta, bands, rows)
-    if extra is not None and extra[0].size:
-        xu, xv = be.to_device(extra[0]), be.to_device(extra[1])
-        be.components_union(labels, xu, xv)
-        eu, ev = torch.cat([eu, xu]), torch.cat([ev, xv])
     be.components_finish(labels)
     removed, n_removed = be.removed_mask(labels, 0, n)
     mark("components")
     return {"sig": sig, "key": key, "meta": meta, "edge_u": eu, "edge_v": ev, "labels": labels,
-            "removed": removed, "n_removed": n_removed, "n_collisions": int(coll_idx.size),
+            "removed": removed, "n_removed": n_removed, "n_collisions": int(n_coll),
             "rec_bucket": rb}
 
 
@@ -157,13 +138,7 @@ def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, ban
     mark("all_to_all")
     # --- local buckets over the records this rank owns
     key_r = be.packed_keys(tuples_r, meta_r, rows, key_bits)
-    eu, ev, coll_idx, _ = be.bucket_edges(key_r, meta_r, tuples_r, 1, rows, 0, rows, False)
-    if coll_idx.size:
-        meta_h = as_u64(meta_r)
-        tup_h = as_u32(tuples_r).reshape(-1, rows)
-        xu, xv = resolve_collisions(coll_idx, meta_h, lambda i: tup_h[i].tobytes())
-        if xu.size:
-            eu, ev = torch.cat([eu, be.to_device(xu)]), torch.cat([ev, be.to_device(xv)])
+    eu, ev, n_coll, _ = be.bucket_edges(key_r, meta_r, tuples_r, 1, rows, 0, rows, False)
     mark("bucket_edges")
     # --- merge: reduce this rank's edges to a spanning forest (at most one edge per touched
     # document), all-gather the forests, identical union-find everywhere
@@ -190,4 +165,4 @@ def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, ban
         timings["forest_edges_local"] = int(eu.numel())
         timings["edges_global"] = int(eu_all.numel())
     return {"sig": sig, "edge_u": eu_all, "edge_v": ev_all, "labels": labels, "removed": removed,
-            "n_removed": n_removed, "n_collisions": int(coll_idx.size)}
+            "n_removed": n_removed, "n_collisions": int(n_coll)}

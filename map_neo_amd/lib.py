@@ -27,7 +27,7 @@ SIGNATURES = {
     "mdd_route_count": (_int, [_vp, _vp, _u64, _int, _vp]),
     "mdd_route_pack": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _u64, _int, _vp, _vp, _vp]),
     "mdd_bucket_edges": (_int, [_vp, _vp, _vp, _u64, _vp, _u64, _u64, _u64, _int, _vp, _u64,
-                                _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
+                                _vp, _vp, _u64, _vp, _vp, _vp]),
     "mdd_components_init": (_int, [_vp, _vp, _u64]),
     "mdd_components_union": (_int, [_vp, _vp, _u64, _vp, _vp, _u64]),
     "mdd_components_finish": (_int, [_vp, _vp, _u64]),

@@ -189,8 +189,8 @@ class Engine:
 
     def bucket_edges(self, key: torch.Tensor, meta: torch.Tensor, tuple_base: torch.Tensor, rec_per_doc: int,
                      doc_stride: int, band_stride: int, rows: int, want_buckets: bool = False):
-        """Returns (edge_u, edge_v int32 device tensors trimmed to n_edges, coll_idx int64 numpy,
-        rec_bucket or None).  Surrogate collisions (coll_idx) are left to the caller."""
+        """Returns (edge_u, edge_v int32 device tensors trimmed to n_edges, number of surrogate-tag collisions
+        met (statistics: buckets are exact), rec_bucket or None)."""
         n_rec = key.numel()
         tab_size = 2
         while tab_size < 2 * max(1, n_rec):
@@ -198,17 +198,14 @@ class Engine:
         table = self.empty(tab_size, torch.int64)
         eu = self.empty(max(1, n_rec), torch.int32)
         ev = self.empty(max(1, n_rec), torch.int32)
-        coll_cap = max(1024, n_rec)
-        coll = self.empty(coll_cap, torch.int64)
         cnt = torch.zeros(2, dtype=torch.int64, device=self.device)
         rb = self.empty(n_rec, torch.int64) if want_buckets else None
         _lib.check(self.L.mdd_bucket_edges(self.ctx, _ptr(key), _ptr(meta), n_rec, _ptr(tuple_base), rec_per_doc,
                                            doc_stride, band_stride, rows, _ptr(table), tab_size,
-                                           _ptr(eu), _ptr(ev), n_rec, C.c_void_p(cnt.data_ptr()), _ptr(coll), coll_cap,
+                                           _ptr(eu), _ptr(ev), n_rec, C.c_void_p(cnt.data_ptr()),
                                            C.c_void_p(cnt.data_ptr() + 8), _ptr(rb)), "mdd_bucket_edges")
         n_edges, n_coll = (int(x) for x in cnt.cpu().tolist())
-        coll_idx = as_u64(coll[:n_coll]).astype(np.int64) if n_coll else np.zeros(0, np.int64)
-        return eu[:n_edges], ev[:n_edges], coll_idx, rb
+        return eu[:n_edges], ev[:n_edges], n_coll, rb
 
     def components_init(self, n_docs: int) -> torch.Tensor:
         labels = self.empty(n_docs, torch.int32)
@@ -434,21 +431,3 @@ class HostPipeline:
         return sig
 
 
-def resolve_collisions(coll_idx: np.ndarray, meta_h: np.ndarray, tuple_of) -> Tuple[np.ndarray, np.ndarray]:
-    """Exact fallback for records whose 64-bit surrogate key collided with a different tuple
-    (expected count ~ n_rec^2 / 2^64).  Every record carrying the same (band, tuple) as a
-    flagged record is flagged too (they all mismatch the same slot representative), so grouping
-    the flagged records by exact (band, tuple) on the host completes the buckets.
-    meta_h: host uint64 meta of all records; tuple_of(i) -> bytes of record i's tuple."""
-    groups = {}
-    for i in coll_idx.tolist():
-        m = int(meta_h[i])
-        groups.setdefault((m >> 56, tuple_of(i)), []).append(m & 0xFFFFFFFF)
-    eu, ev = [], []
-    for docs in groups.values():
-        first = docs[0]
-        for d in docs[1:]:
-            if d != first:
-                eu.append(d)
-                ev.append(first)
-    return np.asarray(eu, np.uint32), np.asarray(ev, np.uint32)

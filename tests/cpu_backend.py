@@ -72,7 +72,7 @@ class OracleBackend:
             else:
                 first[k] = d
         return (self.to_device(np.asarray(eu, np.uint32)), self.to_device(np.asarray(ev, np.uint32)),
-                np.zeros(0, np.int64), None)
+                0, None)
 
     def components_init(self, n):
         return torch.arange(n, dtype=torch.int32)

@@ -50,7 +50,7 @@ def test_invalid_arguments_are_reported(engine):
     cnt = torch.zeros(2, dtype=torch.int64, device=engine.device)
     coll = torch.empty(64, dtype=torch.int64, device=engine.device)
     be = lambda size: L.mdd_bucket_edges(ctx, _p(key), _p(meta), 27, _p(sig), 9, 128, 13, 13, _p(tab), size, _p(eu), _p(eu), 27,
-                                         _p(cnt), _p(coll), 64, C.c_void_p(cnt.data_ptr() + 8), None)
+                                         _p(cnt), C.c_void_p(cnt.data_ptr() + 8), None)
     _fails(L, be(48), "power of two")
     _fails(L, be(32), "power of two")                                          # < 2 * n_rec
     _fails(L, L.mdd_ctx_set_segment_bytes(ctx, 100), "multiple of 256")

@@ -260,8 +260,8 @@ def test_routed_packed_path(engine, mini_docs, mini_expected, world):
         t_r = tuples[start * rows:(start + c) * rows]
         m_r = meta_s[start:start + c]
         k_r = engine.packed_keys(t_r, m_r, rows)
-        eu, ev, coll, _ = engine.bucket_edges(k_r, m_r, t_r, 1, rows, 0, rows)
-        assert coll.size == 0
+        eu, ev, n_coll, _ = engine.bucket_edges(k_r, m_r, t_r, 1, rows, 0, rows)
+        assert n_coll == 0
         engine.components_union(labels, eu, ev)
         start += c
     engine.components_finish(labels)
