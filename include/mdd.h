@@ -178,14 +178,14 @@ int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint6
  * (8-byte aligned, text_bytes long + MDD_TEXT_PAD spare bytes; ranges are clamped to it); units may overlap.
  *   first_of[u] = smallest unit index whose bytes are identical to unit u's (u itself if none).
  * Equal SHA-256 <=> equal bytes, so these are the reference's groups with "first" = lowest index.
- * A 64-bit content hash (truncated to key_bits; pass 64) only picks the table slot; units whose
- * hash collides with a different unit's get first_of[u] = u provisionally and are listed in
- * coll_idx / *n_coll (device u64) for exact resolution by the caller.
+ * A 64-bit content hash (truncated to key_bits; pass 64) only picks the table slot and a 32-bit
+ * tag; a tag match is confirmed by comparing the bytes inside the kernels, so the result is exact.
+ * *n_coll (device u64) counts the tag matches that were different bytes (statistics).
  * Workspaces: key_scratch u64[n_units]; table u64[tab_size], tab_size a power of two
  * >= 2*n_units.  avg_unit_bytes picks thread-per-unit (< 256) or wave-per-unit hashing. */
 int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
                     uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
-                    uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll);
+                    uint32_t* first_of, uint64_t* n_coll);
 
 /* Paragraph dedup.  Replaces paragraph_dedup of
  * Matrix/english_data_clean_pipeline/dedup/Paragraph_Deduplication/paragraph.py:15-30 around

@@ -7,8 +7,8 @@
 //   Exact_Substring_Deduplication/exact_substr_dedup.py:34-47           units = 50-character windows
 // The reference groups on SHA-256 of the unit; equal SHA-256 <=> equal bytes (no collision is
 // known), so grouping on the bytes themselves gives the same groups.  A 64-bit content hash only
-// selects the hash-table slot; membership is decided by comparing the bytes, and units whose
-// hash collides with a different unit's are reported for exact resolution by the caller.
+// selects the hash-table slot and a 32-bit tag; membership is decided by comparing the bytes inside
+// the kernels, so the result is exact and nothing is left to the caller.
 // HBM-bound: every unit's bytes are read once to hash (duplicates once more to verify) plus one
 // random 8-byte atomic and one random 8-byte read per unit.
 #include "mdd_common.h"
@@ -85,85 +85,99 @@ __global__ void __launch_bounds__(256) exact_hash_wave_kernel(const uint64_t* t6
     }
 }
 
-// One 8-byte table entry = (tag << 32 | smallest unit index seen), tag = high half of the key, slot
-// from its low bits: ONE random atomic per unit in the common case (the claim), and one random
-// read per unit in the link pass.  Every device atomic is a full memory transaction here, so
-// the table passes are bound by random-line HBM traffic and halving the transactions halves them.
+// One 8-byte table entry = (tag << 32 | smallest unit index seen), tag = high half of the key, slot from its low
+// bits.  A tag match is confirmed by comparing the BYTES with the entry's unit: different -> just another occupant,
+// keep probing.  So the table is exact (nothing is left to the caller), every slot holds one content for good, and
+// only its unit index shrinks.  ONE random atomic per unit in the common case (the claim) and one random read per
+// unit in the link pass; every device atomic is a full memory transaction, so the table passes are bound by the
+// device's random-access rate, not by bytes.
 constexpr unsigned long long EMPTY = ~0ULL;
 
-__global__ void __launch_bounds__(256) exact_insert_kernel(const uint64_t* key, uint64_t n, unsigned long long* tab, uint64_t tab_mask) {
+__device__ __forceinline__ bool same_unit(const uint64_t* t64, uint64_t b, uint64_t len, uint64_t rb, uint64_t rlen) {
+    if (len != rlen) return false;
+    uint64_t nch = (len + 7) >> 3;
+    for (uint64_t c = 0; c < nch; c++) {
+        uint64_t x = load8(t64, b + 8 * c) ^ load8(t64, rb + 8 * c);
+        uint64_t rem = len - 8 * c;
+        if (rem < 8) x &= (1ULL << (8 * rem)) - 1;
+        if (x) return false;
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) exact_insert_kernel(const uint64_t* t64, uint64_t text_bytes, const uint64_t* ubeg,
+                                                           const uint64_t* uend, const uint64_t* key, uint64_t n,
+                                                           unsigned long long* tab, uint64_t tab_mask, unsigned long long* n_coll) {
     uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n) return;
     uint64_t k = key[u];
     unsigned long long val = (k & 0xFFFFFFFF00000000ULL) | (uint32_t)u;
     uint64_t slot = k & tab_mask;
+    uint64_t b = 0, len = 0;
+    bool have_range = false;
     for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: the table is at most half full
         unsigned long long cur = atomicCAS(&tab[slot], EMPTY, val);
         if (cur == EMPTY) return;
         if ((cur >> 32) == (val >> 32)) {
-            if (cur > val) atomicMin(&tab[slot], val);
-            return;
+            if (!have_range) {
+                unit_range(ubeg, uend, u, text_bytes, b, len);
+                have_range = true;
+            }
+            uint64_t rb, rlen;
+            unit_range(ubeg, uend, (uint32_t)cur, text_bytes, rb, rlen);
+            if (same_unit(t64, b, len, rb, rlen)) {
+                if (cur > val) atomicMin(&tab[slot], val);
+                return;
+            }
+            atomicAdd(n_coll, 1ULL);  // same tag, different bytes: statistics only
         }
         slot = (slot + 1) & tab_mask;
     }
 }
 
 __global__ void __launch_bounds__(256) exact_link_kernel(const uint64_t* t64, uint64_t text_bytes, const uint64_t* ubeg,
-                                                         const uint64_t* uend, const uint64_t* key, uint64_t n, const unsigned long long* tab,
-                                                         uint64_t tab_mask, uint32_t* first_of, uint64_t* coll_idx,
-                                                         uint64_t coll_cap, unsigned long long* n_coll) {
+                                                         const uint64_t* uend, const uint64_t* key, uint64_t n,
+                                                         const unsigned long long* tab, uint64_t tab_mask, uint32_t* first_of) {
     uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n) return;
     uint64_t k = key[u];
     uint64_t slot = k & tab_mask;
-    uint32_t rep = (uint32_t)u;
+    uint32_t out = (uint32_t)u;
+    uint64_t b = 0, len = 0;
+    bool have_range = false;
     for (uint64_t probe = 0; probe <= tab_mask; probe++) {
         unsigned long long cur = tab[slot];
-        if (cur == EMPTY) break;
+        if (cur == EMPTY) break;  // cannot happen after the insert pass; defensive
         if ((cur >> 32) == (k >> 32)) {
-            rep = (uint32_t)cur;
-            break;
+            if ((uint32_t)cur == (uint32_t)u) break;  // this unit is the first of its group
+            if (!have_range) {
+                unit_range(ubeg, uend, u, text_bytes, b, len);
+                have_range = true;
+            }
+            uint64_t rb, rlen;
+            unit_range(ubeg, uend, (uint32_t)cur, text_bytes, rb, rlen);
+            if (same_unit(t64, b, len, rb, rlen)) {
+                out = (uint32_t)cur;
+                break;
+            }
         }
         slot = (slot + 1) & tab_mask;
-    }
-    uint32_t out = (uint32_t)u;
-    if (rep != (uint32_t)u) {
-        uint64_t b, len, rb, rlen;
-        unit_range(ubeg, uend, u, text_bytes, b, len);
-        unit_range(ubeg, uend, rep, text_bytes, rb, rlen);
-        bool same = len == rlen;
-        uint64_t nch = (len + 7) >> 3;
-        for (uint64_t c = 0; same && c < nch; c++) {
-            uint64_t x = load8(t64, b + 8 * c), y = load8(t64, rb + 8 * c);
-            uint64_t rem = len - 8 * c;
-            if (rem < 8) {
-                uint64_t m = (1ULL << (8 * rem)) - 1;
-                x &= m;
-                y &= m;
-            }
-            same = x == y;
-        }
-        if (same) out = rep;
-        else {
-            unsigned long long o = atomicAdd(n_coll, 1ULL);
-            if (o < coll_cap) coll_idx[o] = u;
-        }
     }
     first_of[u] = out;
 }
 
 }  // namespace
 
-extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
-                               uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
-                               uint32_t* first_of, uint64_t* coll_idx, uint64_t coll_cap, uint64_t* n_coll) {
+extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* ubeg, const uint64_t* uend,
+                               uint64_t n_units, uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table,
+                               uint64_t tab_size, uint32_t* first_of, uint64_t* n_coll) {
     REQUIRE(ctx && n_coll, "mdd_exact_group: NULL argument");
     REQUIRE(key_bits >= 1 && key_bits <= 64, "mdd_exact_group: key_bits=%d outside [1,64]", key_bits);
     REQUIRE(n_units <= MAX_ELEMS_PER_LAUNCH, "mdd_exact_group: n_units=%llu exceeds 2^32-256", (unsigned long long)n_units);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(n_coll, 0, sizeof(uint64_t), ctx->stream));
     if (n_units == 0) return MDD_OK;
-    REQUIRE(text && ubeg && uend && key_scratch && table && first_of && (coll_cap == 0 || coll_idx), "mdd_exact_group: NULL buffer");
+    REQUIRE(text && ubeg && uend && key_scratch && table && first_of, "mdd_exact_group: NULL buffer");
     REQUIRE((reinterpret_cast<uintptr_t>(text) & 7u) == 0, "mdd_exact_group: text must be 8-byte aligned");
     REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_units,
             "mdd_exact_group: tab_size=%llu must be a power of two >= 2*n_units", (unsigned long long)tab_size);
@@ -180,12 +194,11 @@ extern "C" int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
     unsigned g = grid_for(n_units, 256);
-    hipLaunchKernelGGL(exact_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key_scratch, n_units,
-                       reinterpret_cast<unsigned long long*>(table), tab_size - 1);
+    hipLaunchKernelGGL(exact_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg, uend, key_scratch, n_units,
+                       reinterpret_cast<unsigned long long*>(table), tab_size - 1, reinterpret_cast<unsigned long long*>(n_coll));
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(exact_link_kernel, dim3(g), dim3(256), 0, ctx->stream, t64, text_bytes, ubeg, uend, key_scratch, n_units,
-                       reinterpret_cast<const unsigned long long*>(table), tab_size - 1, first_of, coll_idx, coll_cap,
-                       reinterpret_cast<unsigned long long*>(n_coll));
+                       reinterpret_cast<const unsigned long long*>(table), tab_size - 1, first_of);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

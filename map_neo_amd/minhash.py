@@ -239,10 +239,12 @@ class Engine:
 
     def exact_group(self, text: torch.Tensor, ubeg: torch.Tensor, uend: torch.Tensor, key_bits: int = 64,
                     text_host: Optional[np.ndarray] = None) -> torch.Tensor:
-        """first_of[u] = smallest unit index with bytes identical to unit u (int32 tensor, u32 bits).
-        Hash collisions between different units are resolved exactly on the host."""
+        """first_of[u] = smallest unit index with bytes identical to unit u (int32 tensor, u32 bits).  Exact: hash
+        tag matches are confirmed on the bytes inside the kernels (`last_exact_collisions` counts the false ones).
+        `text_host` is accepted for compatibility and unused."""
         n = ubeg.numel()
         first_of = self.empty(n, torch.int32)
+        self.last_exact_collisions = 0
         if n == 0:
             return first_of
         total = int((uend - ubeg).sum().item())
@@ -251,24 +253,11 @@ class Engine:
             tab_size *= 2
         key = self.empty(n, torch.int64)
         table = self.empty(tab_size, torch.int64)
-        coll = self.empty(max(1024, n), torch.int64)
         cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
-        _lib.check(self.L.mdd_exact_group(self.ctx, _ptr(text), max(0, text.numel() - TEXT_PAD), _ptr(ubeg), _ptr(uend), n, total // n, key_bits, _ptr(key),
-                                          _ptr(table), tab_size, _ptr(first_of), _ptr(coll), coll.numel(), _ptr(cnt)),
-                   "mdd_exact_group")
-        n_coll = int(cnt.item())
-        if n_coll:
-            idx = as_u64(coll[:n_coll]).astype(np.int64)
-            th = text_host if text_host is not None else text.cpu().numpy()
-            b, e = ubeg.cpu().numpy(), uend.cpu().numpy()
-            groups = {}
-            for u in np.sort(idx).tolist():
-                groups.setdefault(th[b[u]:e[u]].tobytes(), []).append(u)
-            fo = as_u32(first_of).copy()
-            for members in groups.values():
-                fo[members] = members[0]
-            first_of = self.to_device(fo)
-        self.last_exact_collisions = n_coll
+        _lib.check(self.L.mdd_exact_group(self.ctx, _ptr(text), max(0, text.numel() - TEXT_PAD), _ptr(ubeg), _ptr(uend), n,
+                                          max(0, total) // n, key_bits, _ptr(key), _ptr(table), tab_size, _ptr(first_of),
+                                          _ptr(cnt)), "mdd_exact_group")
+        self.last_exact_collisions = int(cnt.item())
         return first_of
 
     def paragraph_dedup(self, text: torch.Tensor, offsets: torch.Tensor, min_len: int = 20, key_bits: int = 64):

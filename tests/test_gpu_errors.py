@@ -54,8 +54,7 @@ def test_invalid_arguments_are_reported(engine):
     _fails(L, be(48), "power of two")
     _fails(L, be(32), "power of two")                                          # < 2 * n_rec
     _fails(L, L.mdd_ctx_set_segment_bytes(ctx, 100), "multiple of 256")
-    _fails(L, L.mdd_exact_group(ctx, _p(text), tb, _p(o), _p(o), 3, 10, 64, _p(key), _p(tab), 4, _p(eu), _p(coll), 64, _p(cnt)),
-           "power of two")
+    _fails(L, L.mdd_exact_group(ctx, _p(text), tb, _p(o), _p(o), 3, 10, 64, _p(key), _p(tab), 4, _p(eu), _p(cnt)), "power of two")
     with pytest.raises(mlib.MddError):
         engine.signatures(text[: tb + 8], o, text_bytes=tb)                   # missing MDD_TEXT_PAD
     engine.sync()

@@ -28,7 +28,7 @@ def test_exact_group_primitive(engine):
     buf, offs = pack_texts(units)
     first = {}
     exp = np.array([first.setdefault(u, i) for i, u in enumerate(units)], dtype=np.uint32)
-    for key_bits in (64, 6):                                                  # 6 bits: massive slot collisions, host resolution
+    for key_bits in (64, 6):                                                  # 6 bits: massive tag collisions, settled on the bytes
         got = as_u32(engine.exact_group(engine.to_device(buf), engine.to_device(offs[:-1].copy()),
                                         engine.to_device(offs[1:].copy()), key_bits, text_host=buf))
         assert (got == exp).all(), key_bits
