@@ -58,3 +58,41 @@ def test_random_configurations(engine, seed):
     assert (as_u32(out["sig"]).reshape(len(docs), K) == exp_sig).all(), (K, unit, width, seg)
     exp_labels, _ = RC.cluster(exp_sig, bands, rows)
     assert (as_u32(out["labels"]) == exp_labels).all(), (K, bands, rows)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_exact_stages(engine, seed):
+    """seeded random sweep over window length, minimum lengths, segment length and random utf-8 documents built
+    from shared pieces (so that windows / paragraphs repeat): fused kernels == oracle restatement"""
+    from map_neo_amd import exact, hostio
+    from oracle import ref_exact as RX
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    pieces = _docs(rng, 40)
+    pieces = [p.replace("\n", " ") for p in pieces if p] or ["x"]
+    docs = []
+    for _ in range(80):
+        k = int(rng.integers(0, 6))
+        sep = "\n" if rng.random() < 0.7 else ""
+        docs.append(sep.join(pieces[int(i)] for i in rng.integers(0, len(pieces), k)) + ("\n" if rng.random() < 0.2 else ""))
+    window = int(rng.choice([1, 2, 13, 50, 50, 64, 128]))
+    min_length = int(rng.choice([0, 1, 20, 200]))
+    seg = int(rng.choice([0, 256, 1024]))
+    engine.set_segment_bytes(seg)
+    try:
+        rows = [(d, i) for i, d in enumerate(docs)]
+        assert exact.exact_substr_dedup(engine, rows, window, min_length) == RX.exact_substr_dedup(rows, window, min_length), \
+            (window, min_length, seg)
+    finally:
+        engine.set_segment_bytes(0)
+    ids = [int(i) for i in rng.permutation(len(docs))]
+    prow = list(zip(ids, docs))
+    assert exact.paragraph_dedup(engine, prow, min_length) == RX.paragraph_dedup(prow, min_length), min_length
+    assert exact.exact_document_dedup(engine, docs).tolist() == RX.exact_document_dedup(docs)
+    # device EN normalisation on the ASCII documents of the sweep
+    ascii_docs = [d for d in docs if d.isascii()]
+    if ascii_docs:
+        buf, offs = pack_texts(ascii_docs)
+        t, o, f = engine.normalize_en(engine.to_device(buf), engine.to_device(offs))
+        raw, oo = t.cpu().numpy().tobytes(), o.cpu().numpy()
+        assert not f.any().item()
+        assert [raw[int(oo[k]):int(oo[k + 1])].decode() for k in range(len(ascii_docs))] == [hostio.normalize_text(d) for d in ascii_docs]
