@@ -867,10 +867,10 @@ int mdd_band_keys(mdd_ctx* ctx, const uint32_t* sig, uint64_t n_docs, int K, int
 
 int mdd_packed_keys(mdd_ctx* ctx, const uint32_t* tuples, const uint64_t* meta, uint64_t n_rec, int rows, int key_bits,
                     uint64_t* key) {
-    REQUIRE(ctx && key, "mdd_packed_keys: NULL argument");
+    REQUIRE(ctx, "mdd_packed_keys: ctx is NULL");
     REQUIRE(rows >= 1 && key_bits >= 1 && key_bits <= 64, "mdd_packed_keys: bad rows/key_bits");
-    if (n_rec == 0) return MDD_OK;
-    REQUIRE(tuples && meta, "mdd_packed_keys: NULL records");
+    if (n_rec == 0) return MDD_OK;  // a rank that received no records
+    REQUIRE(tuples && meta && key, "mdd_packed_keys: NULL records");
     REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_packed_keys: n_rec exceeds one launch (2^32-256)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(packed_keys_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, ctx->stream, tuples, meta, n_rec, rows,

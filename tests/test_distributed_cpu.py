@@ -76,9 +76,11 @@ stage.run(args, engine_factory=lambda device: OracleBackend())
 '''
 
 
-def test_stage_cli_two_ranks_gloo(tmp_path, mini_docs):
+@pytest.mark.parametrize("world", [2, 5])
+def test_stage_cli_two_ranks_gloo(tmp_path, mini_docs, world):
     """The stage entry point under torchrun with 2 ranks (oracle-backed CPU backend, gloo): every rank ingests
-    its block of shards; ids / clusters / surviving rows equal the single-process oracle result"""
+    its block of shards; ids / clusters / surviving rows equal the single-process oracle result.  With 5 ranks
+    and 4 shards one rank has no documents at all."""
     import gzip
     from oracle import ref_py as R
     n = len(mini_docs)
@@ -93,8 +95,8 @@ def test_stage_cli_two_ranks_gloo(tmp_path, mini_docs):
     script = tmp_path / "cli_worker.py"
     script.write_text(CLI_WORKER.format(root=ROOT, inp=str(inp), out=str(out)))
     port = 31500 + (os.getpid() % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port + world), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lab = R.dedup(mini_docs)["labels"]
@@ -118,4 +120,4 @@ def test_stage_cli_two_ranks_gloo(tmp_path, mini_docs):
     rows = [json.loads(l) for p in sorted(os.listdir(out / "shards")) for l in gzip.open(out / "shards" / p, "rt", encoding="utf8")]
     assert sorted(r["doc_id"] for r in rows) == sorted(set(ids) - exp_removed)
     s = json.load(open(out / "summary.json"))
-    assert s["world"] == 2 and s["n_rows"] == n and s["n_removed_ids"] == len(exp_removed) and s["kept_rows_written"] == len(rows)
+    assert s["world"] == world and s["n_rows"] == n and s["n_removed_ids"] == len(exp_removed) and s["kept_rows_written"] == len(rows)

@@ -354,3 +354,22 @@ def test_forest_edges(engine):
     engine.components_finish(l2)
     assert (as_u32(l2) == lab).all()
     assert (lab == R.components_min_label(n, [(int(u), int(v)) for u, v in edges if u != v])).all()
+
+
+def test_distributed_steps_with_an_empty_shard(engine):
+    """a rank without documents (more ranks than shards) walks the same calls with zero records"""
+    sig = torch.empty((0, 128), dtype=torch.int32, device=engine.device)
+    key, meta = engine.band_keys(sig, 9, 13, 5)
+    assert key.numel() == 0 and meta.numel() == 0
+    tuples, meta_s, counts = engine.route(sig, key, meta, 9, 13, 8)
+    assert counts.tolist() == [0] * 8 and tuples.numel() == 0
+    k = engine.packed_keys(tuples, meta_s, 13)
+    eu, ev, n_coll, _ = engine.bucket_edges(k, meta_s, tuples, 1, 13, 0, 13)
+    assert eu.numel() == 0 and n_coll == 0
+    labels = engine.components_init(10)
+    engine.components_union(labels, eu, ev)
+    engine.components_finish(labels)
+    fu, fv = engine.forest_edges(labels, 0)
+    assert fu.numel() == 0 and as_u32(labels).tolist() == list(range(10))
+    removed, n_removed = engine.removed_mask(labels, 10, 0)
+    assert removed.numel() == 0 and int(n_removed.item()) == 0
