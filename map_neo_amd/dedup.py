@@ -76,28 +76,66 @@ def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = N
     return cluster_local(be, sig, bands, rows, key_bits, want_buckets, timer)
 
 
-def _all_to_all_v(t: torch.Tensor, send_counts, recv_counts, width: int, group=None):
+# RCCL on this stack silently drops the tail of an all_to_all_single message beyond 1 GiB (measured with one rank:
+# everything past the first half of a 1 GiB + 8 KiB message arrives untouched, tools/diag_a2a.py), so no single
+# collective call here moves more than COLLECTIVE_BYTES in total; larger exchanges run in rounds.
+COLLECTIVE_BYTES = 256 << 20
+
+
+def _all_to_all_v(t: torch.Tensor, send_counts, recv_counts, width: int, group=None, limit_bytes: Optional[int] = None):
+    """Variable all-to-all of records of `width` elements: t holds the records for peer 0, peer 1, ... back to back
+    (send_counts records each); returns what the peers sent here, grouped by peer (recv_counts)."""
     import torch.distributed as dist
-    out = torch.empty(int(sum(recv_counts)) * width, dtype=t.dtype, device=t.device)
-    dist.all_to_all_single(out, t, [int(c) * width for c in recv_counts], [int(c) * width for c in send_counts],
-                           group=group)
+    world = len(send_counts)
+    send_counts = [int(c) for c in send_counts]
+    recv_counts = [int(c) for c in recv_counts]
+    out = torch.empty(sum(recv_counts) * width, dtype=t.dtype, device=t.device)
+    per_peer = max(1, (limit_bytes or COLLECTIVE_BYTES) // (t.element_size() * width * world))   # records per peer per round
+    mx = torch.tensor([max(send_counts + recv_counts + [0])], dtype=torch.int64, device=t.device)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)       # every rank must run the same number of rounds
+    rounds = max(1, -(-int(mx.item()) // per_peer))
+    if rounds == 1:
+        dist.all_to_all_single(out, t, [c * width for c in recv_counts], [c * width for c in send_counts], group=group)
+        return out
+    s_off = [0] * world
+    r_off = [0] * world
+    for p in range(1, world):
+        s_off[p] = s_off[p - 1] + send_counts[p - 1]
+        r_off[p] = r_off[p - 1] + recv_counts[p - 1]
+    for k in range(rounds):
+        s_cnt = [min(max(c - k * per_peer, 0), per_peer) for c in send_counts]
+        r_cnt = [min(max(c - k * per_peer, 0), per_peer) for c in recv_counts]
+        sbuf = torch.cat([t[(s_off[p] + k * per_peer) * width: (s_off[p] + k * per_peer + s_cnt[p]) * width] for p in range(world)])
+        rbuf = torch.empty(sum(r_cnt) * width, dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(rbuf, sbuf, [c * width for c in r_cnt], [c * width for c in s_cnt], group=group)
+        pos = 0
+        for p in range(world):
+            out[(r_off[p] + k * per_peer) * width: (r_off[p] + k * per_peer + r_cnt[p]) * width] = rbuf[pos: pos + r_cnt[p] * width]
+            pos += r_cnt[p] * width
     return out
 
 
-def _all_gather_v(t: torch.Tensor, group=None):
-    """All-gather of variable-length 1-D tensors (sizes exchanged first)."""
+def _all_gather_v(t: torch.Tensor, group=None, limit_bytes: Optional[int] = None):
+    """All-gather of variable-length 1-D tensors (sizes exchanged first), in rounds of bounded size."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-    pad[: t.numel()] = t
-    outs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(outs, pad, group=group)
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)])
+    per_rank = max(1, (limit_bytes or COLLECTIVE_BYTES) // (t.element_size() * world))
+    parts = [[] for _ in range(world)]
+    for lo in range(0, max(max(sizes), 1), per_rank):
+        cnt = [min(max(s - lo, 0), per_rank) for s in sizes]
+        mx = max(max(cnt), 1)
+        pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+        mine = t[lo: lo + per_rank]
+        pad[: mine.numel()] = mine
+        outs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(outs, pad, group=group)
+        for p in range(world):
+            parts[p].append(outs[p][: cnt[p]])
+    return torch.cat([x for p in range(world) for x in parts[p]])
 
 
 def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: int, n_global: int,

@@ -368,3 +368,30 @@ def test_full_text_dedup_cli(tmp_path):
     got = [l for p in parts for l in open(tmp_path / "o" / p, encoding="utf8")]
     assert got == exp and st["n_kept"] == len(exp) and st["n_without_content"] == 1
     assert parts[:-1] == [f"part_{i}.jsonl" for i in range(len(parts) - 1)] and parts[-1] == f"part_{len(parts) - 1}"
+
+
+def test_rccl_exchange_larger_than_one_gib(tmp_path):
+    """RCCL's all_to_all_single drops the tail of a message beyond 1 GiB (seen with one rank); the exchange helper
+    must move 1.3 GiB intact by running in rounds"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "a2a.py"
+    script.write_text(f'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from map_neo_amd.dedup import _all_to_all_v, _all_gather_v
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+n = 27_000_000                      # records of 13 x int32 = 1.31 GiB
+x = torch.arange(n * 13, dtype=torch.int32, device="cuda")
+y = _all_to_all_v(x, [n], [n], 13)
+assert torch.equal(x, y)
+g = _all_gather_v(x[: 100_000_000], limit_bytes=64 << 20)
+assert torch.equal(g, x[: 100_000_000])
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
