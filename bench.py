@@ -280,6 +280,7 @@ def main():
     # PCIe-inclusive figure (reported, never `value`): time one H2D of the packed text from pinned host memory
     h2d_ms = None
     pipelined_sig_ms = None
+    pipelined_equal = None
     if rank == 0 and world == 1 and text_bytes < (8 << 30) and not args.no_pcie:
         try:
             host = torch.empty(text.numel(), dtype=torch.uint8, pin_memory=True)
@@ -304,6 +305,7 @@ def main():
             sig_p = pipe.signatures(host, offs_h, K, WIDTH, "char")
             torch.cuda.synchronize()
             pipelined_sig_ms = (time.perf_counter() - tp) * 1e3
+            pipelined_equal = bool(torch.equal(sig_p, eng.signatures(text, offsets, K, WIDTH, "char", text_bytes=text_bytes)))
             del host, sig_p, pipe
         except Exception as e:  # pinned allocation can fail on small hosts: the figures are optional
             print(f"[bench] PCIe figures skipped: {e}", file=sys.stderr)
@@ -391,10 +393,14 @@ def main():
                        "path": "distributed (RCCL all-to-all + all-gather)" if use_dist else "single-GPU"},
             "text_gb_per_s": text_bytes * world / (dt / args.steps) / 1e9,
             "n_removed": n_removed,
+            # cross-check that survives any path: the generator injected this many (near-)duplicates; a path that loses
+            # band records or edges removes visibly fewer documents than that
+            "n_injected_duplicates": int(spec.is_dup.sum()),
             "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stages.items()},
             "corpus_gen_s": t_gen,
             "h2d_text_ms": h2d_ms,
             "signatures_from_pinned_host_ms": pipelined_sig_ms,
+            "signatures_from_pinned_host_equal_resident": pipelined_equal,
             "pcie_inclusive_docs_per_s": (n_local / ((ms_per_step + h2d_ms) * 1e-3)) if (h2d_ms and world == 1) else None,
             "roofline": {"bound": "valu", "kernel": "sig_kernel<2,false>", "achieved": achieved, "peak": PEAK_VALU_TOPS,
                          "unit": "Tops/s (int32 lane-ops)", "frac": (achieved / PEAK_VALU_TOPS) if achieved else None,
