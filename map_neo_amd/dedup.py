@@ -78,8 +78,8 @@ def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = N
 
 # RCCL on this stack silently drops the tail of an all_to_all_single message beyond 1 GiB (measured with one rank:
 # everything past the first half of a 1 GiB + 8 KiB message arrives untouched, tools/diag_a2a.py), so no single
-# collective call here moves more than COLLECTIVE_BYTES in total; larger exchanges run in rounds.
-COLLECTIVE_BYTES = 256 << 20
+# collective call here moves more than COLLECTIVE_BYTES (half the observed limit) in total; larger exchanges run in rounds.
+COLLECTIVE_BYTES = 512 << 20
 
 
 def _all_to_all_v(t: torch.Tensor, send_counts, recv_counts, width: int, group=None, limit_bytes: Optional[int] = None):
