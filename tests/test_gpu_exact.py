@@ -172,3 +172,33 @@ def test_exact_group_more_than_2_pow_26_long_units(engine):
     first = engine.exact_group(text, ubeg, uend)
     assert engine.last_exact_collisions == 0
     assert torch.equal(first.to(torch.int64), u % 1000)
+
+
+def test_substr_partitioned_passes_equal_single_pass_at_scale(engine):
+    """200 k synthetic documents (0.4 GB, 0.4 G windows): one table pass vs seven key-partitioned passes"""
+    import torch
+    from map_neo_amd import corpus
+    spec = corpus.CorpusSpec(200_000, 2048, lang="en", seed=5)
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    a = engine.substr_dedup(text, offs, 50, 20)
+    assert engine.last_substr_parts == 1
+    n_win = int(torch.clamp(offs[1:] - offs[:-1] - 50, min=0).sum().item())
+    b = engine.substr_dedup(text, offs, 50, 20, table_bytes=16 * n_win // 7 + 1)
+    assert engine.last_substr_parts == 7
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    n = int(a[1][-1].item())
+    assert torch.equal(a[0][:n], b[0][:n]) and 0 < n < int(offs[-1].item())
+    del b
+    # and the independent generic route (explicit unit ranges through mdd_exact_group + torch plumbing)
+    g = exact.exact_substr_dedup_packed(engine, text, offs, 50, 20, fused=False)
+    assert torch.equal(a[1], g[1]) and torch.equal(a[2], g[2]) and torch.equal(a[0][:n], g[0][:n])
+    del g
+    # paragraphs: every 40th space becomes a newline
+    par = text.clone()
+    body = par[: int(offs[-1].item())]
+    r = torch.rand(body.numel(), device=engine.device, generator=torch.Generator(device=engine.device).manual_seed(3))
+    body.copy_(torch.where((body == 32) & (r < 0.025), torch.full_like(body, 10), body))
+    pa = exact.paragraph_dedup_packed(engine, par, offs, 20, fused=True)
+    pg = exact.paragraph_dedup_packed(engine, par, offs, 20, fused=False)
+    m = int(pa[1][-1].item())
+    assert torch.equal(pa[1], pg[1]) and torch.equal(pa[2], pg[2]) and torch.equal(pa[0][:m], pg[0][:m]) and m > 0
