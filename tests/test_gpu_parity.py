@@ -373,3 +373,44 @@ def test_distributed_steps_with_an_empty_shard(engine):
     assert fu.numel() == 0 and as_u32(labels).tolist() == list(range(10))
     removed, n_removed = engine.removed_mask(labels, 10, 0)
     assert removed.numel() == 0 and int(n_removed.item()) == 0
+
+
+def test_segmented_long_documents_equal_unsegmented_at_scale(engine):
+    """20 k documents of ~20 KB (C5 shape): default 16 KiB segments (several waves + atomicMin per document) vs one
+    wave per document -- identical signatures; K = 256 is checked as well"""
+    spec = corpus.CorpusSpec(20_000, 20_480, lang="mixed", seed=9)
+    text, offs = corpus.generate_chunked(spec, engine.device, docs_per_chunk=2048)
+    for K in (128, 256):
+        a = engine.signatures(text, offs, K)
+        engine.set_segment_bytes(1 << 24)
+        try:
+            b = engine.signatures(text, offs, K)
+        finally:
+            engine.set_segment_bytes(0)
+        assert torch.equal(a, b)
+    assert int((offs[1:] - offs[:-1]).max().item()) > 16384
+
+
+def test_routed_path_equals_local_path_at_scale(engine):
+    """300 k documents: band records routed to 8 owners, bucketed per owner in PACKED layout and merged through
+    spanning forests == the single-GPU bucket stage (labels, hence removed set)"""
+    spec = corpus.CorpusSpec(300_000, 1024, lang="mixed", seed=13)
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    out = dedup_local(engine, text, offs)
+    sig, n = out["sig"], spec.n_docs
+    key, meta = engine.band_keys(sig, 9, 13, 0)
+    tuples, meta_s, counts = engine.route(sig, key, meta, 9, 13, 8)
+    labels = engine.components_init(n)
+    start = 0
+    for c in counts.tolist():
+        t_r, m_r = tuples[start * 13:(start + c) * 13], meta_s[start:start + c]
+        eu, ev, _, _ = engine.bucket_edges(engine.packed_keys(t_r, m_r, 13), m_r, t_r, 1, 13, 0, 13)
+        lab = engine.components_init(n)                   # per-owner forest, as cluster_distributed ships it
+        engine.components_union(lab, eu, ev)
+        engine.components_finish(lab)
+        fu, fv = engine.forest_edges(lab, int(eu.numel()))
+        engine.components_union(labels, fu, fv)
+        start += c
+    engine.components_finish(labels)
+    assert torch.equal(labels, out["labels"])
+    assert int(out["n_removed"].item()) > 0.3 * int(spec.is_dup.sum())     # LSH at ~0.8 Jaccard misses the more heavily edited copies
