@@ -82,10 +82,20 @@ def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = N
 COLLECTIVE_BYTES = 512 << 20
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """gloo carries CUDA tensors through the host anyway and was seen to dead-lock with several ranks on one GPU
+    (rehearsals of the multi-rank path on a one-GPU box): with that backend the exchanges below are staged
+    explicitly through host memory.  RCCL (backend "nccl") always works on the device buffers."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _all_to_all_v(t: torch.Tensor, send_counts, recv_counts, width: int, group=None, limit_bytes: Optional[int] = None):
     """Variable all-to-all of records of `width` elements: t holds the records for peer 0, peer 1, ... back to back
     (send_counts records each); returns what the peers sent here, grouped by peer (recv_counts)."""
     import torch.distributed as dist
+    if _host_staged(t, group):
+        return _all_to_all_v(t.cpu(), send_counts, recv_counts, width, group, limit_bytes).to(t.device)
     world = len(send_counts)
     send_counts = [int(c) for c in send_counts]
     recv_counts = [int(c) for c in recv_counts]
@@ -118,6 +128,8 @@ def _all_to_all_v(t: torch.Tensor, send_counts, recv_counts, width: int, group=N
 def _all_gather_v(t: torch.Tensor, group=None, limit_bytes: Optional[int] = None):
     """All-gather of variable-length 1-D tensors (sizes exchanged first), in rounds of bounded size."""
     import torch.distributed as dist
+    if _host_staged(t, group):
+        return _all_gather_v(t.cpu(), group, limit_bytes).to(t.device)
     world = dist.get_world_size(group)
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
@@ -169,7 +181,12 @@ def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, ban
     send_counts = [int(c) for c in send_counts.tolist()]
     sc = torch.tensor(send_counts, dtype=torch.int64, device=meta_s.device)
     rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
+    if _host_staged(sc, group):
+        sc_h, rc_h = sc.cpu(), rc.cpu()
+        dist.all_to_all_single(rc_h, sc_h, group=group)
+        rc = rc_h.to(sc.device)
+    else:
+        dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(c) for c in rc.tolist()]
     tuples_r = _all_to_all_v(tuples_s, send_counts, recv_counts, rows, group)
     meta_r = _all_to_all_v(meta_s, send_counts, recv_counts, 1, group)

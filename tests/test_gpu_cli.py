@@ -395,3 +395,57 @@ print("ok")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+DIST_REHEARSAL = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from map_neo_amd import corpus
+from map_neo_amd.dedup import dedup_distributed, dedup_local
+from map_neo_amd.minhash import Engine
+dist.init_process_group("gloo")                    # gloo moves CUDA tensors too: all ranks share GPU 0, the kernels are the real ones
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+eng = Engine(0)
+n = 60000
+spec = corpus.CorpusSpec(n, 600, lang="mixed", seed=31, dup_frac=0.2, edit_rate=0.005)
+bounds = [0, 9000, 9000, 31000, n] if world == 4 else [(n * r) // world for r in range(world + 1)]    # uneven, one empty rank
+lo, hi = bounds[rank], bounds[rank + 1]
+text, offs = corpus.generate(spec, lo, hi, eng.device) if hi > lo else (torch.zeros(256, dtype=torch.uint8, device=eng.device), torch.zeros(1, dtype=torch.int64, device=eng.device))
+for K, bands, rows in ((128, 9, 13), (256, 20, 12)):
+    out = dedup_distributed(eng, text, offs, lo, n, K, 13, "char", bands, rows)
+    labels = out["labels"]
+    removed_local = int(out["n_removed"].item())
+    tot = torch.tensor([removed_local], dtype=torch.int64)
+    dist.all_reduce(tot)
+    if rank == 0:
+        ft, fo = corpus.generate(spec, 0, n, eng.device)
+        ref = dedup_local(eng, ft, fo, K, 13, "char", bands, rows)
+        assert torch.equal(labels, ref["labels"]), (K, bands)
+        assert int(tot.item()) == int(ref["n_removed"].item()) > 1000, (int(tot.item()), int(ref["n_removed"].item()))
+    # every rank holds the same labels
+    chk = labels.to(torch.int64).sum().reshape(1).cpu()
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    assert len({{int(c.item()) for c in allc}}) == 1
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_multi_rank_rehearsal_with_real_kernels(tmp_path, world):
+    """dedup_distributed with the real HIP engine on several ranks (gloo carries the CUDA tensors; all ranks share
+    GPU 0): uneven shards incl. an empty rank, two (K, bands, rows) settings; labels == the single-GPU path"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rehearsal.py"
+    script.write_text(DIST_REHEARSAL.format(root=root))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 100 + world), str(script)]
+    # gloo picks its interface from the host name, which does not always resolve on the GPU boxes: pin it to loopback
+    env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
+    assert r.returncode == 0 and r.stdout.count("ok") >= world, r.stdout[-1500:] + r.stderr[-4000:]
