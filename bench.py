@@ -245,6 +245,11 @@ def main():
     from map_neo_amd.dedup import StageTimer, dedup_distributed, dedup_local
     from map_neo_amd.minhash import Engine, padded_size
 
+    # rehearsal of the multi-rank script on a one-GPU box: MDD_BENCH_BACKEND=gloo puts every rank on GPU 0 and lets
+    # gloo carry the tensors (the driver's runs use the default: one GPU per rank, RCCL)
+    backend = os.environ.get("MDD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -252,7 +257,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     eng = Engine(local_rank)
     dev = eng.device
 

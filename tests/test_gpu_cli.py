@@ -449,3 +449,28 @@ def test_multi_rank_rehearsal_with_real_kernels(tmp_path, world):
     env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
     assert r.returncode == 0 and r.stdout.count("ok") >= world, r.stdout[-1500:] + r.stderr[-4000:]
+
+
+def test_bench_script_multi_rank_rehearsal():
+    """bench.py exactly as the driver launches it for N > 1 (torchrun, one rank per process), rehearsed on one GPU over
+    gloo: ONE JSON line from rank 0, whole-job figures, and the same removed count as the single-GPU run of the same
+    global corpus"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDD_BENCH_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+    port = str(29850 + os.getpid() % 100)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", port, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--docs", "50000"],
+                       capture_output=True, text=True, timeout=200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    multi = json.loads(lines[0])
+    assert multi["n_gpus"] == 4 and multi["config"]["global_docs"] == 200000 and multi["scaling"] == "weak"
+    assert multi["vs_baseline"] is None and "cpu_baseline" not in multi
+    r1 = subprocess.run([sys.executable, "bench.py", "--docs", "200000", "--no-cpu", "--no-pcie", "--no-stages", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=200, env=dict(os.environ), cwd=root)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    single = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert multi["n_removed"] == single["n_removed"] > 0.5 * single["n_injected_duplicates"]
