@@ -133,11 +133,12 @@ def run(args, engine_factory=None) -> dict:
 
         from ..dedup import cluster_distributed, cluster_local
         from ..minhash import as_u32, padded_size
+        backend = os.environ.get("MDD_DIST_BACKEND", "nccl")     # "gloo": rehearsal with every rank on --device (one-GPU box)
         if engine_factory is not None:
             eng = engine_factory(local_rank)
         else:
             from ..minhash import Engine
-            eng = Engine(local_rank if distributed else args.device)
+            eng = Engine(local_rank if (distributed and backend == "nccl") else args.device)
         dist = None
         if distributed:
             import torch.distributed as dist
@@ -146,7 +147,7 @@ def run(args, engine_factory=None) -> dict:
                 os.environ.setdefault("MASTER_PORT", "29533")
                 os.environ.setdefault("RANK", "0")
                 os.environ.setdefault("WORLD_SIZE", "1")
-                if eng.device.type == "cuda":
+                if eng.device.type == "cuda" and backend == "nccl":
                     dist.init_process_group("nccl", device_id=eng.device)
                 else:
                     dist.init_process_group("gloo")

@@ -474,3 +474,32 @@ def test_bench_script_multi_rank_rehearsal():
     assert r1.returncode == 0, r1.stderr[-3000:]
     single = json.loads(r1.stdout.strip().splitlines()[-1])
     assert multi["n_removed"] == single["n_removed"] > 0.5 * single["n_injected_duplicates"]
+
+
+def test_stage_cli_multi_rank_rehearsal(tmp_path, mini_docs):
+    """`torchrun -m map_neo_amd.cli.dedup` with 3 ranks and the real engine (gloo, all ranks on GPU 0): the stitched
+    outputs equal the single-process run's"""
+    import subprocess
+    import sys
+    n = len(mini_docs)
+    ids = [f"id{(i * 37) % n:04d}" for i in range(n)]
+    inp = tmp_path / "in"
+    inp.mkdir()
+    for f, (a, b) in enumerate([(0, 30), (30, 90), (90, 140), (140, 170), (170, n)]):
+        _write_jsonl(inp / f"s{f}.jsonl", [{"doc_id": ids[i], "raw_content": mini_docs[i]} for i in range(a, b)])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = ["--input_dir", str(inp), "--normalize", "none", "--workers", "3", "--write_shards"]
+    env = dict(os.environ, PYTHONPATH=root, MDD_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29950 + os.getpid() % 40), "-m", "map_neo_amd.cli.dedup", "--output_dir", str(tmp_path / "multi")] + base,
+                       capture_output=True, text=True, timeout=200, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    r1 = subprocess.run([sys.executable, "-m", "map_neo_amd.cli.dedup", "--output_dir", str(tmp_path / "single")] + base,
+                        capture_output=True, text=True, timeout=200, env=dict(os.environ, PYTHONPATH=root), cwd=root)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    for name in ("kept_ids.txt", "removed_ids.txt", "clusters.jsonl"):
+        assert open(tmp_path / "multi" / name).read() == open(tmp_path / "single" / name).read(), name
+    assert sorted(os.listdir(tmp_path / "multi" / "shards")) == sorted(os.listdir(tmp_path / "single" / "shards"))
+    for p in os.listdir(tmp_path / "single" / "shards"):
+        assert gzip.open(tmp_path / "multi" / "shards" / p).read() == gzip.open(tmp_path / "single" / "shards" / p).read()
+    assert json.load(open(tmp_path / "multi" / "summary.json"))["world"] == 3
