@@ -300,7 +300,7 @@ def test_stage_entry_point_distributed_one_rank(tmp_path, mini_docs):
         out = tmp_path / mode
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), PYTHONPATH=root)
         r = subprocess.run([sys.executable, "-m", "map_neo_amd.cli.dedup", "--input_dir", str(inp), "--output_dir", str(out),
-                            "--normalize", "none", "--workers", "2"] + extra, capture_output=True, text=True, timeout=300,
+                            "--normalize", "none", "--workers", "2"] + extra, capture_output=True, text=True, timeout=120,
                            env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         outs[mode] = {name: open(out / name, encoding="utf8").read() for name in ("kept_ids.txt", "removed_ids.txt", "clusters.jsonl")}
@@ -393,7 +393,7 @@ dist.barrier(); dist.destroy_process_group()
 print("ok")
 ''')
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), RANK="0", WORLD_SIZE="1")
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
@@ -447,7 +447,7 @@ def test_multi_rank_rehearsal_with_real_kernels(tmp_path, world):
            "--master-port", str(29800 + os.getpid() % 100 + world), str(script)]
     # gloo picks its interface from the host name, which does not always resolve on the GPU boxes: pin it to loopback
     env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and r.stdout.count("ok") >= world, r.stdout[-1500:] + r.stderr[-4000:]
 
 
@@ -462,7 +462,7 @@ def test_bench_script_multi_rank_rehearsal():
     port = str(29850 + os.getpid() % 100)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                         "--master-port", port, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--docs", "50000"],
-                       capture_output=True, text=True, timeout=200, env=env, cwd=root)
+                       capture_output=True, text=True, timeout=120, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -470,7 +470,7 @@ def test_bench_script_multi_rank_rehearsal():
     assert multi["n_gpus"] == 4 and multi["config"]["global_docs"] == 200000 and multi["scaling"] == "weak"
     assert multi["vs_baseline"] is None and "cpu_baseline" not in multi
     r1 = subprocess.run([sys.executable, "bench.py", "--docs", "200000", "--no-cpu", "--no-pcie", "--no-stages", "--steps", "1", "--warmup", "0"],
-                        capture_output=True, text=True, timeout=200, env=dict(os.environ), cwd=root)
+                        capture_output=True, text=True, timeout=120, env=dict(os.environ), cwd=root)
     assert r1.returncode == 0, r1.stderr[-3000:]
     single = json.loads(r1.stdout.strip().splitlines()[-1])
     assert multi["n_removed"] == single["n_removed"] > 0.5 * single["n_injected_duplicates"]
@@ -492,10 +492,10 @@ def test_stage_cli_multi_rank_rehearsal(tmp_path, mini_docs):
     env = dict(os.environ, PYTHONPATH=root, MDD_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
                         "--master-port", str(29950 + os.getpid() % 40), "-m", "map_neo_amd.cli.dedup", "--output_dir", str(tmp_path / "multi")] + base,
-                       capture_output=True, text=True, timeout=200, env=env, cwd=root)
+                       capture_output=True, text=True, timeout=120, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     r1 = subprocess.run([sys.executable, "-m", "map_neo_amd.cli.dedup", "--output_dir", str(tmp_path / "single")] + base,
-                        capture_output=True, text=True, timeout=200, env=dict(os.environ, PYTHONPATH=root), cwd=root)
+                        capture_output=True, text=True, timeout=120, env=dict(os.environ, PYTHONPATH=root), cwd=root)
     assert r1.returncode == 0, r1.stderr[-3000:]
     for name in ("kept_ids.txt", "removed_ids.txt", "clusters.jsonl"):
         assert open(tmp_path / "multi" / name).read() == open(tmp_path / "single" / name).read(), name
