@@ -195,9 +195,18 @@ def run(args, engine_factory=None) -> dict:
         mine = np.flatnonzero(in_cluster[doc_base: doc_base + n])
         pairs = [(int(labels[doc_base + k]), cand_ids[k], doc_base + int(k)) for k in mine.tolist()]
         if distributed:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, pairs)
-            all_pairs = [p for part in gathered for p in part]
+            # in rounds of 200 k entries per rank: all_gather_object pickles into one message per call, and no
+            # collective call here should come near 1 GiB (map_neo_amd.dedup.COLLECTIVE_BYTES)
+            chunk = 200_000
+            lens = [None] * world
+            dist.all_gather_object(lens, len(pairs))
+            all_parts = [[] for _ in range(world)]
+            for lo in range(0, max(max(lens), 1), chunk):
+                gathered = [None] * world
+                dist.all_gather_object(gathered, pairs[lo: lo + chunk])
+                for r, part in enumerate(gathered):
+                    all_parts[r].extend(part)
+            all_pairs = [p for part in all_parts for p in part]
         else:
             all_pairs = pairs
         # representative: smallest id (EN:145) unless ids were synthesised, then first in input order
