@@ -202,3 +202,17 @@ def test_substr_partitioned_passes_equal_single_pass_at_scale(engine):
     pg = exact.paragraph_dedup_packed(engine, par, offs, 20, fused=False)
     m = int(pa[1][-1].item())
     assert torch.equal(pa[1], pg[1]) and torch.equal(pa[2], pg[2]) and torch.equal(pa[0][:m], pg[0][:m]) and m > 0
+
+
+def test_exact_stages_match_golden_fixture(engine):
+    """HIP path against the committed fixture tests/golden/exact_expected.json"""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exact_expected.json"), encoding="utf8"))
+    ids, docs = g["ids"], g["docs"]
+    assert exact.exact_document_dedup(engine, docs).tolist() == g["exact_document_keep"]
+    for fused in (True, False):
+        assert [list(x) for x in exact.paragraph_dedup(engine, list(zip(ids, docs)), 20, fused=fused)] == g["paragraph_min_len_20"]
+        assert [list(x) for x in exact.paragraph_dedup(engine, list(zip(ids, docs)), 0, fused=fused)] == g["paragraph_min_len_0"]
+        assert [list(x) for x in exact.exact_substr_dedup(engine, list(zip(docs, ids)), 50, 20, fused=fused)] == g["substr_50_20"]
+        assert [list(x) for x in exact.exact_substr_dedup(engine, list(zip(docs, ids)), 13, 0, fused=fused)] == g["substr_13_0"]

@@ -166,3 +166,17 @@ def test_c_oracle_multithreaded_equals_single(mini_docs):
     from oracle import ref_c as RC
     buf, offs = pack_texts(mini_docs)
     assert (RC.signatures(buf, offs, threads=4) == RC.signatures(buf, offs)).all()
+
+
+def test_exact_stage_oracle_matches_golden():
+    """oracle/ref_exact.py against the committed fixture (tests/golden/make_golden_exact.py)"""
+    import json
+    import os
+    from oracle import ref_exact as RX
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exact_expected.json"), encoding="utf8"))
+    ids, docs = g["ids"], g["docs"]
+    assert RX.exact_document_dedup(docs) == g["exact_document_keep"]
+    assert [list(x) for x in RX.paragraph_dedup(list(zip(ids, docs)), 20)] == g["paragraph_min_len_20"]
+    assert [list(x) for x in RX.paragraph_dedup(list(zip(ids, docs)), 0)] == g["paragraph_min_len_0"]
+    assert [list(x) for x in RX.exact_substr_dedup(list(zip(docs, ids)), 50, 20)] == g["substr_50_20"]
+    assert [list(x) for x in RX.exact_substr_dedup(list(zip(docs, ids)), 13, 0)] == g["substr_13_0"]
