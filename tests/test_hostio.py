@@ -196,3 +196,42 @@ def test_parquet_shard_reader_leaves_invalid_utf8_rows_unhashed(tmp_path):
     r = hostio.read_parquet_shard(path, "raw_content", "doc_id")
     assert r["cand"].tolist() == [0, 2, 3] and r["ids"] == [f"d{i}" for i in range(5)]
     assert bytes(r["text"]) == b"good onecaf\xc3\xa9" and r["offsets"].tolist() == [0, 8, 8, 13]
+
+
+def test_native_reader_equals_python_reader_property(tmp_path):
+    """hypothesis: arbitrary JSON rows (unicode incl. astral and control characters, nested values, duplicate-looking
+    keys, both ensure_ascii settings, optional gzip) -- the native scanner + fallback must return exactly what the
+    pure-Python reader returns, with and without EN normalisation"""
+    import gzip
+    import json
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from map_neo_amd import hostio
+    if hostio._io() is None:
+        pytest.skip("libmdd_io.so not built")
+    text = st.text(alphabet=st.characters(blacklist_categories=("Cs",)), max_size=80)
+    scalar = st.one_of(st.none(), st.booleans(), st.integers(-10**12, 10**12), st.floats(allow_nan=False, allow_infinity=False), text)
+    value = st.recursive(scalar, lambda c: st.one_of(st.lists(c, max_size=3), st.dictionaries(text, c, max_size=3)), max_leaves=6)
+    row = st.fixed_dictionaries({}, optional={"doc_id": st.one_of(text, st.integers(0, 10**9), st.none()),
+                                              "raw_content": st.one_of(text, st.none(), st.integers()),
+                                              "extra": value, "raw_content2": text})
+    counter = [0]
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(rows=st.lists(row, max_size=12), ascii_=st.booleans(), gz=st.booleans(), blank=st.booleans())
+    def run(rows, ascii_, gz, blank):
+        counter[0] += 1
+        path = str(tmp_path / f"h{counter[0]}.jsonl{'.gz' if gz else ''}")
+        lines = [json.dumps(r, ensure_ascii=ascii_) for r in rows]
+        if blank:
+            lines.insert(len(lines) // 2, "   ")
+        data = ("\n".join(lines) + ("\n" if lines else "")).encode("utf8")
+        with (gzip.open(path, "wb") if gz else open(path, "wb")) as f:
+            f.write(data)
+        for norm in (False, True):
+            a = hostio.read_jsonl_shard(path, "raw_content", "doc_id", normalize_en=norm, use_native=True)
+            b = hostio.read_jsonl_shard(path, "raw_content", "doc_id", normalize_en=norm, use_native=False)
+            assert a["ids"] == b["ids"] and a["n_bad"] == b["n_bad"]
+            assert a["line_no"].tolist() == b["line_no"].tolist() and a["cand"].tolist() == b["cand"].tolist()
+            assert a["offsets"].tolist() == b["offsets"].tolist() and bytes(a["text"]) == bytes(b["text"])
+
+    run()
