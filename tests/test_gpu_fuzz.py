@@ -96,3 +96,18 @@ def test_random_exact_stages(engine, seed):
         raw, oo = t.cpu().numpy().tobytes(), o.cpu().numpy()
         assert not f.any().item()
         assert [raw[int(oo[k]):int(oo[k + 1])].decode() for k in range(len(ascii_docs))] == [hostio.normalize_text(d) for d in ascii_docs]
+
+
+@pytest.mark.parametrize("unit,width", [("char", 128), ("char", 100), ("word", 128), ("word", 32)])
+def test_maximum_widths(engine, unit, width):
+    """the widest shingles the ABI accepts (ring occupancy 64 + width + 256 boundary entries; multi-block SHA-1)"""
+    rng = np.random.Generator(np.random.PCG64(77 + width))
+    docs = _docs(rng, 60) + ["a " * 700, "字" * 300, "x" * 127, "x" * 128, "x" * 129, " ".join(["w"] * 127), " ".join(["w"] * 129)]
+    buf, offs = pack_texts(docs)
+    for seg in (0, 256):
+        engine.set_segment_bytes(seg)
+        try:
+            sig = engine.signatures(engine.to_device(buf), engine.to_device(offs), 64, width, unit)
+        finally:
+            engine.set_segment_bytes(0)
+        assert (as_u32(sig).reshape(len(docs), 64) == RC.signatures(buf, offs, 64, width, unit)).all(), (unit, width, seg)
