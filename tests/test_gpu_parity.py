@@ -414,3 +414,33 @@ def test_routed_path_equals_local_path_at_scale(engine):
     engine.components_finish(labels)
     assert torch.equal(labels, out["labels"])
     assert int(out["n_removed"].item()) > 0.3 * int(spec.is_dup.sum())     # LSH at ~0.8 Jaccard misses the more heavily edited copies
+
+
+def test_single_huge_document(engine):
+    """one 24 MB document (about 1 500 segments of 16 KiB) next to a 6 MB CJK one: segment size must not matter, and
+    the exact substring stage must erase a verbatim second copy"""
+    from map_neo_amd import exact
+    rng = np.random.Generator(np.random.PCG64(91))
+    words = np.array(["w%d" % i for i in range(5000)])
+    big = " ".join(rng.choice(words, 4_000_000))                       # ~24 MB ASCII
+    zh = "".join(chr(int(c)) for c in rng.integers(0x4E00, 0x9FFF, 2_000_000))     # 6 MB of 3-byte code points
+    buf, offs = pack_texts([big, zh, "tiny"])
+    text, o = engine.to_device(buf), engine.to_device(offs)
+    ref = engine.signatures(text, o, 128)
+    for seg in (4096, 1 << 20, 1 << 26):
+        engine.set_segment_bytes(seg)
+        try:
+            assert torch.equal(engine.signatures(text, o, 128), ref), seg
+        finally:
+            engine.set_segment_bytes(0)
+    assert torch.equal(engine.signatures(text, o, 256)[:, :128], ref)
+    # substring dedup: [big, big] -> every window of the copy is a repeat; only its last code point is uncovered
+    # (SUB:38 never hashes the last window), which is below min_length, so the copy goes (same on a small case by the oracle)
+    from oracle import ref_exact
+    small = big[:20_000]
+    assert ref_exact.exact_substr_dedup([(small, "a"), (small, "b")], 50, 20) == [("a", small)]
+    buf2, offs2 = pack_texts([big, big])
+    t2, o2, docs = exact.exact_substr_dedup_packed(engine, engine.to_device(buf2), engine.to_device(offs2), 50, 20)
+    assert docs.tolist() == [0]
+    kept = bytes(t2[: int(o2[1].item())].cpu().numpy()).decode()
+    assert len(big) - len(kept) < 5000 and kept[:1000] == big[:1000] and kept[-50:] == big[-50:]
