@@ -415,6 +415,12 @@ def main():
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                          "algorithmic_bytes": text_bytes + 8 * (n_local + 1) + 4 * K * n_local, "kernel_ms": sig_ms,
                          "algorithmic_ops_per_shingle": OPS_PER_SHINGLE(K),
+                         "hbm_view": ({"bound": "hbm", "achieved": (text_bytes + 8 * (n_local + 1) + 4 * K * n_local) / (sig_ms * 1e6),
+                                       "peak": 8000.0, "unit": "GB/s",
+                                       "frac": (text_bytes + 8 * (n_local + 1) + 4 * K * n_local) / (sig_ms * 1e6) / 8000.0,
+                                       "note": "the same launch priced against HBM: <1 % of 8 TB/s, i.e. the kernel is "
+                                               "nowhere near memory-bound; ~2 750 integer ops per text byte put it on the VALU"}
+                                      if sig_ms else None),
                          "issue_slot_utilisation": (n_shingles * ISSUE_SLOTS_PER_SHINGLE(K) / 78.6e12 / (sig_ms * 1e-3))
                          if sig_ms else None,
                          "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz simple int32 lane-ops; frac can exceed 1 because "

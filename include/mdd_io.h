@@ -65,6 +65,25 @@ uint64_t mdd_io_n_docs(const mdd_io_shard* s);
 const uint8_t* mdd_io_text(const mdd_io_shard* s);
 const uint64_t* mdd_io_offsets(const mdd_io_shard* s);    /* [n_docs+1] */
 
+/* ---- egress: the output side of the exact-match stages ------------------------------------
+ * Replaces the reference's  df.select(doc_id, raw_content).write.json(path, compression="gzip")
+ * (paragraph.py:27-28,33-36; exact_substr_dedup.py:92-95) for one output part.  Writes n_docs
+ * lines
+ *     {<key_id_json>: <id k>, <key_content_json>: "<content k, JSON-escaped>"}\n
+ * byte for byte what Python's  json.dumps(row, ensure_ascii=False) + "\n"  produces: ", " and
+ * ": " separators, only  "  \  and the control characters below 0x20 escaped (\b \f \n \r \t,
+ * \u00XX for the rest), everything else copied as utf-8.
+ *   key_id_json / key_content_json   the two keys already JSON-encoded (quotes included)
+ *   ids_json[ids_bytes]              the n_docs id values already JSON-encoded, separated by one
+ *                                    '\n' (a JSON value never holds a raw newline)
+ *   text / offsets[n_docs+1]         packed utf-8 contents: document k = text[offsets[k], offsets[k+1])
+ *   gzip_level                       1-9: gzip member at that zlib level; 0: plain file
+ * Contents that are not valid utf-8 (Python's .decode("utf8") would raise) fail the call with
+ * a negative code and leave no file behind.  *bytes_out = uncompressed bytes written. */
+int mdd_io_write_jsonl(const char* path, const char* key_id_json, const char* key_content_json, const uint8_t* ids_json,
+                       uint64_t ids_bytes, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs, int gzip_level,
+                       uint64_t* bytes_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,8 +3,6 @@ paragraph, exact_substr_dedup): shard ingest into one packed corpus in HBM and g
 output.  The corpus of one invocation is held in host memory once and in HBM once."""
 from __future__ import annotations
 
-import gzip
-import json
 import multiprocessing as mp
 import os
 
@@ -78,27 +76,36 @@ def reorder_packed(text, offs, perm):
 
 def _write_part(task):
     out_path, ids, raw, offs = task
-    with gzip.open(out_path, "wt", encoding="utf8", compresslevel=6) as f:
-        for k, rid in enumerate(ids):
-            row = {DOC_ID_FIELD_NAME: rid, CONTENT_FIELD_NAME: raw[int(offs[k]) - int(offs[0]): int(offs[k + 1]) - int(offs[0])].decode("utf8")}
-            f.write(json.dumps(row, ensure_ascii=False) + "\n")
-    return len(ids)
+    from .. import hostio
+    return hostio.write_jsonl_part(out_path, DOC_ID_FIELD_NAME, CONTENT_FIELD_NAME, ids, raw, offs)
 
 
 def write_docs(output_dir: str, ids, text, offs, workers: int, docs_per_part: int = 0) -> int:
     """gzip JSON lines {"doc_id", "raw_content"} (the two columns PAR:27-28 / SUB:92 keep); the part size is chosen
-    so that every worker gets several parts (gzip is the slow step), at most 100k documents each"""
+    so that every worker gets several parts (gzip is the slow step), at most 100k documents each.  With
+    libmdd_io.so the parts are written by threads straight from the one host copy of the text (the native writer
+    runs without the GIL); without it by spawned processes running the equivalent Python loop."""
+    from multiprocessing.pool import ThreadPool
+    from .. import hostio
     os.makedirs(output_dir, exist_ok=True)
     if docs_per_part <= 0:
         docs_per_part = min(100_000, max(1000, -(-len(ids) // (4 * max(1, workers)))))
-    raw, o = text.cpu().numpy(), offs.cpu().numpy()
+    raw, o = text.cpu().numpy(), offs.cpu().numpy().astype(np.uint64)
+    native = hostio._io() is not None
     tasks = []
     for p, k0 in enumerate(range(0, len(ids), docs_per_part)):
         k1 = min(len(ids), k0 + docs_per_part)
-        tasks.append((os.path.join(output_dir, "part-%05d.json.gz" % p), ids[k0:k1], raw[int(o[k0]):int(o[k1])].tobytes(), o[k0:k1 + 1]))
+        path = os.path.join(output_dir, "part-%05d.json.gz" % p)
+        if native:
+            tasks.append((path, ids[k0:k1], raw, o[k0:k1 + 1]))
+        else:
+            tasks.append((path, ids[k0:k1], raw[int(o[k0]):int(o[k1])].copy(), o[k0:k1 + 1] - o[k0]))
     if not tasks:
         return 0
     if workers <= 1 or len(tasks) == 1:
         return sum(map(_write_part, tasks))
+    if native:
+        with ThreadPool(min(workers, len(tasks))) as pool:
+            return sum(pool.map(_write_part, tasks))
     with mp.get_context("spawn").Pool(min(workers, len(tasks))) as pool:   # the parent holds a GPU context: never fork it
         return sum(pool.map(_write_part, tasks))

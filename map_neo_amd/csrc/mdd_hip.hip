@@ -1002,26 +1002,31 @@ int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint6
 int mdd_valu_calibrate(mdd_ctx* ctx, int iters, double* tops_host) {
     REQUIRE(ctx && tops_host && iters > 0, "mdd_valu_calibrate: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    uint32_t* out = nullptr;
-    HIP_TRY(hipMalloc(&out, 256));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    struct Scratch {  // released on every return path
+        uint32_t* out = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scratch() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (out) (void)hipFree(out);
+        }
+    } s;
+    HIP_TRY(hipMalloc(&s.out, 256));
+    HIP_TRY(hipEventCreate(&s.e0));
+    HIP_TRY(hipEventCreate(&s.e1));
     unsigned blocks = (unsigned)ctx->cus * 8;
-    hipLaunchKernelGGL(valu_cal_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, 64, 1u);
+    hipLaunchKernelGGL(valu_cal_kernel, dim3(blocks), dim3(256), 0, ctx->stream, s.out, 64, 1u);
+    HIP_TRY(hipGetLastError());
     float best = 1e30f;
     for (int rep = 0; rep < 3; rep++) {
-        HIP_TRY(hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(valu_cal_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, iters, 1u);
-        HIP_TRY(hipEventRecord(e1, ctx->stream));
-        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventRecord(s.e0, ctx->stream));
+        hipLaunchKernelGGL(valu_cal_kernel, dim3(blocks), dim3(256), 0, ctx->stream, s.out, iters, 1u);
+        HIP_TRY(hipEventRecord(s.e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(s.e1));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
         if (ms < best) best = ms;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(out);
     double ops = (double)blocks * 256.0 * (double)iters * 4 * 8 * 2;
     *tops_host = ops / (best * 1e-3) / 1e12;
     return MDD_OK;

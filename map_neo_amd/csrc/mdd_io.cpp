@@ -458,6 +458,105 @@ int mdd_io_read_jsonl(const char* path, const char* content_field, const char* i
     return 0;
 }
 
+int mdd_io_write_jsonl(const char* path, const char* key_id_json, const char* key_content_json, const uint8_t* ids_json,
+                       uint64_t ids_bytes, const uint8_t* text, const uint64_t* offsets, uint64_t n_docs, int gzip_level,
+                       uint64_t* bytes_out) {
+    if (!path || !key_id_json || !key_content_json || !bytes_out) return fail(-1, "mdd_io_write_jsonl: NULL argument");
+    if (n_docs && (!ids_json || !offsets)) return fail(-1, "mdd_io_write_jsonl: NULL ids / offsets");
+    if (gzip_level < 0 || gzip_level > 9) return fail(-1, "mdd_io_write_jsonl: gzip_level=%d outside [0,9]", gzip_level);
+    *bytes_out = 0;
+    gzFile g = nullptr;
+    FILE* f = nullptr;
+    if (gzip_level > 0) {
+        char mode[8];
+        snprintf(mode, sizeof mode, "wb%d", gzip_level);
+        g = gzopen(path, mode);
+        if (g) gzbuffer(g, 1 << 18);
+    } else {
+        f = fopen(path, "wb");
+    }
+    if (!g && !f) return fail(-2, "mdd_io_write_jsonl: cannot create %s", path);
+
+    static const char HEX[] = "0123456789abcdef";
+    const size_t FLUSH = 1 << 20;
+    std::vector<uint8_t> buf;
+    buf.reserve(FLUSH + (1 << 16));
+    const std::string head = std::string("{") + key_id_json + ": ", mid = std::string(", ") + key_content_json + ": \"";
+    uint64_t total = 0;
+    int rc = 0;
+    auto flush = [&]() -> bool {
+        if (buf.empty()) return true;
+        bool ok = g ? gzwrite(g, buf.data(), (unsigned)buf.size()) == (int)buf.size()
+                    : fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        total += buf.size();
+        buf.clear();
+        return ok;
+    };
+    const uint8_t* idp = ids_json;
+    const uint8_t* const id_end = ids_json + ids_bytes;
+    for (uint64_t k = 0; k < n_docs && rc == 0; k++) {
+        if (k > 0) {
+            if (idp >= id_end) { rc = fail(-1, "mdd_io_write_jsonl: %llu ids for %llu documents", (unsigned long long)k, (unsigned long long)n_docs); break; }
+            idp++;  // the separator
+        }
+        const uint8_t* idq = (const uint8_t*)memchr(idp, '\n', (size_t)(id_end - idp));
+        if (!idq) idq = id_end;
+        if (idq == idp) { rc = fail(-1, "mdd_io_write_jsonl: id %llu is empty", (unsigned long long)k); break; }
+        buf.insert(buf.end(), head.begin(), head.end());
+        buf.insert(buf.end(), idp, idq);
+        idp = idq;
+        buf.insert(buf.end(), mid.begin(), mid.end());
+        if (offsets[k + 1] < offsets[k]) { rc = fail(-1, "mdd_io_write_jsonl: offsets decrease at document %llu", (unsigned long long)k); break; }
+        Scanner sc{text + offsets[k], text + offsets[k + 1]};
+        while (sc.p < sc.end) {
+            // longest run that is copied verbatim
+            const uint8_t* run = sc.p;
+            while (sc.p < sc.end && *sc.p >= 0x20 && *sc.p < 0x80 && *sc.p != '"' && *sc.p != '\\') sc.p++;
+            buf.insert(buf.end(), run, sc.p);
+            if (sc.p >= sc.end) break;
+            uint8_t c = *sc.p;
+            if (c >= 0x80) {
+                const uint8_t* s0 = sc.p;
+                if (!sc.utf8_seq()) { rc = fail(-3, "mdd_io_write_jsonl: document %llu is not valid utf-8 at byte %llu", (unsigned long long)k, (unsigned long long)(s0 - (text + offsets[k]))); break; }
+                buf.insert(buf.end(), s0, sc.p);
+                continue;
+            }
+            sc.p++;
+            buf.push_back('\\');
+            switch (c) {
+                case '"': buf.push_back('"'); break;
+                case '\\': buf.push_back('\\'); break;
+                case '\b': buf.push_back('b'); break;
+                case '\f': buf.push_back('f'); break;
+                case '\n': buf.push_back('n'); break;
+                case '\r': buf.push_back('r'); break;
+                case '\t': buf.push_back('t'); break;
+                default:
+                    buf.push_back('u');
+                    buf.push_back('0');
+                    buf.push_back('0');
+                    buf.push_back(HEX[c >> 4]);
+                    buf.push_back(HEX[c & 15]);
+            }
+        }
+        if (rc) break;
+        buf.push_back('"');
+        buf.push_back('}');
+        buf.push_back('\n');
+        if (buf.size() >= FLUSH && !flush()) rc = fail(-2, "mdd_io_write_jsonl: write to %s failed", path);
+    }
+    if (rc == 0 && n_docs && idp != id_end) rc = fail(-1, "mdd_io_write_jsonl: more ids than the %llu documents", (unsigned long long)n_docs);
+    if (rc == 0 && !flush()) rc = fail(-2, "mdd_io_write_jsonl: write to %s failed", path);
+    bool closed = g ? gzclose(g) == Z_OK : fclose(f) == 0;
+    if (rc == 0 && !closed) rc = fail(-2, "mdd_io_write_jsonl: closing %s failed", path);
+    if (rc) {
+        remove(path);
+        return rc;
+    }
+    *bytes_out = total;
+    return 0;
+}
+
 void mdd_io_free(mdd_io_shard* s) { delete s; }
 uint64_t mdd_io_n_lines(const mdd_io_shard* s) { return s->status.size(); }
 const uint8_t* mdd_io_status(const mdd_io_shard* s) { return s->status.data(); }

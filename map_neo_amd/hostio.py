@@ -113,8 +113,54 @@ def _io():
         for name in ("status", "line_no", "line_begin", "line_end", "id_kind", "id_begin", "id_end", "raw", "text", "offsets"):
             f = getattr(L, "mdd_io_" + name)
             f.argtypes, f.restype = [C.c_void_p], C.c_void_p
+        L.mdd_io_write_jsonl.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                         C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+        L.mdd_io_write_jsonl.restype = C.c_int
         _io_lib = L
     return _io_lib or None
+
+
+_SCALAR_IDS = (str, int, float, bool, type(None))
+
+
+def write_jsonl_part(path: str, id_field: str, content_field: str, ids, raw: np.ndarray, offsets: np.ndarray,
+                     gzip_level: int = 6, native: bool = True) -> int:
+    """One output part of the exact-match stages: line k = json.dumps({id_field: ids[k], content_field:
+    raw[offsets[k]:offsets[k+1]].decode("utf8")}, ensure_ascii=False) + "\n", gzip'ed (the columns PAR:27-28 /
+    SUB:92 keep).  libmdd_io.so writes it without the GIL (callers run parts on threads); the Python loop below
+    is the same thing and is what runs when the library is absent or native=False.  -> documents written"""
+    import json
+    import numpy as np
+    n = len(ids)
+    assert offsets.shape[0] == n + 1
+    L = _io() if native else None
+    if L is None:
+        with (gzip.open(path, "wt", encoding="utf8", compresslevel=gzip_level, newline="\n") if gzip_level else
+              open(path, "w", encoding="utf8", newline="\n")) as f:
+            mv = memoryview(raw)
+            for k, rid in enumerate(ids):
+                row = {id_field: rid, content_field: bytes(mv[int(offsets[k]): int(offsets[k + 1])]).decode("utf8")}
+                f.write(json.dumps(row, ensure_ascii=False) + "\n")
+        return n
+    import ctypes as C
+    if all(type(x) in _SCALAR_IDS for x in ids):
+        # one C-encoder call for all ids; a raw newline cannot occur inside an encoded scalar, so it separates them
+        blob = json.dumps(list(ids), ensure_ascii=False, separators=("\n", ": "))[1:-1].encode("utf8") if n else b""
+    else:
+        blob = "\n".join(json.dumps(x, ensure_ascii=False) for x in ids).encode("utf8")
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    if n and int(offsets[-1]) > raw.size:
+        raise ValueError("write_jsonl_part: offsets run past the text")
+    written = C.c_uint64(0)
+    rc = L.mdd_io_write_jsonl(path.encode(), json.dumps(id_field, ensure_ascii=False).encode("utf8"),
+                              json.dumps(content_field, ensure_ascii=False).encode("utf8"), blob, len(blob),
+                              raw.ctypes.data, offsets.ctypes.data, n, gzip_level, C.byref(written))
+    if rc == -3:
+        raise UnicodeDecodeError("utf-8", b"", 0, 1, L.mdd_io_last_error().decode("utf8", "replace"))
+    if rc != 0:
+        raise OSError(L.mdd_io_last_error().decode("utf8", "replace"))
+    return n
 
 
 def _py_line(line: str, content_field: str, id_field, normalize_en: bool, on_error: str):

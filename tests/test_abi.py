@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
     assert L.mdd_version() >= 100
 
 
+def test_io_library_exports_every_declared_symbol():
+    """include/mdd_io.h (native ingest / egress) against libmdd_io.so"""
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdd_io.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mdd_io_[a-z0-9_]+)\s*\(", src)))
+    assert len(syms) >= 17 and "mdd_io_write_jsonl" in syms
+    L = C.CDLL(os.path.join(ROOT, "map_neo_amd", "libmdd_io.so"))
+    for s in syms:
+        assert hasattr(L, s), f"libmdd_io.so lacks {s}"
+
+
 def test_make_perms_matches_golden(golden_perms):
     from map_neo_amd.minhash import make_perms
     a, b = make_perms(1, 256)

@@ -2,6 +2,7 @@
 input.  The native scanner must either agree with json.loads or hand the line back."""
 import gzip
 import json
+import os
 
 import numpy as np
 import pytest
@@ -235,3 +236,50 @@ def test_native_reader_equals_python_reader_property(tmp_path):
             assert a["offsets"].tolist() == b["offsets"].tolist() and bytes(a["text"]) == bytes(b["text"])
 
     run()
+
+
+def test_native_writer_equals_python_writer(tmp_path):
+    """mdd_io_write_jsonl (egress of the exact-match stages) against json.dumps(row, ensure_ascii=False) line by line:
+    escapes, control characters, non-BMP, empty documents, scalar and nested ids, keys that need escaping,
+    part sub-ranges of a shared text buffer, plain and gzip output, invalid utf-8"""
+    import gzip
+    from map_neo_amd import hostio
+    if hostio._io() is None:
+        pytest.skip("libmdd_io.so not built")
+    rng = np.random.default_rng(3)
+    docs = ["", "plain", 'q"uote\\back', "ctl\x00\x01\x1f\x7f\n\r\t\b\f", "é漢字😀  ", "a" * 70000, "퟿"]
+    for _ in range(500):
+        cps = rng.integers(0, 0x3000, int(rng.integers(0, 200)))
+        docs.append("".join(chr(int(c)) for c in cps))
+    ids = ["id%d" % i for i in range(len(docs))]
+    ids[3], ids[4], ids[5], ids[6], ids[7] = 'we"ird\nid', 17, None, 1.5, True
+    enc = [d.encode() for d in docs]
+    raw = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+
+    def both(idf, cf, ids_, offs_, level):
+        hostio.write_jsonl_part(a, idf, cf, ids_, raw, offs_, level, native=True)
+        hostio.write_jsonl_part(b, idf, cf, ids_, raw, offs_, level, native=False)
+        op = gzip.open if level else open
+        with op(a, "rb") as fa, op(b, "rb") as fb:
+            A, B = fa.read(), fb.read()
+        assert A == B
+        return A
+
+    for level in (6, 1, 0):
+        A = both("doc_id", "raw_content", ids, offs, level)
+        rows = [json.loads(l) for l in A.decode().split("\n") if l]
+        assert [r["raw_content"] for r in rows] == docs and [r["doc_id"] for r in rows] == ids
+    both('i"d', "c\\té", [[1, "a\nb"], {"k": "v"}] + ids[2:], offs, 6)          # nested ids, keys needing escapes
+    both("doc_id", "raw_content", ids[5:9], offs[5:10], 6)                           # a part in the middle of the buffer
+    assert both("doc_id", "raw_content", [], offs[:1], 6) == b""
+    bad = np.frombuffer(b"ok\xff\xfe" + "퟿".encode() + b"\xed\xa0\x80", dtype=np.uint8)
+    for o in ([0, 4], [4, 10]):                                                      # stray bytes; utf-8 encoded surrogate
+        for nat in (False, True):
+            with pytest.raises(UnicodeDecodeError):
+                hostio.write_jsonl_part(a, "doc_id", "raw_content", ["x"], bad, np.array(o, np.uint64), 6, native=nat)
+    assert not os.path.exists(a)                                                     # the native writer leaves no partial file
+    with pytest.raises(OSError):
+        hostio.write_jsonl_part(str(tmp_path / "no" / "dir"), "doc_id", "raw_content", ["x"], raw, offs[:2], 6)
