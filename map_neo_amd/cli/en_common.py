@@ -26,14 +26,25 @@ def load_corpus(input_dir: str, workers: int, device: int = 0, content_field: st
     rows_per_file [(ids, line_no, cand)]"""
     from .. import hostio
     files = hostio.list_files(input_dir)
-    pool = mp.get_context("fork").Pool(max(1, workers))       # forked before this process touches the GPU
-    try:
-        parsed = pool.map(_parse, [(p, content_field, id_field) for p in files])
-    finally:
-        pool.close()
-        pool.join()
-    from ..minhash import Engine, padded_size
-    eng = Engine(device)
+    tasks = [(p, content_field, id_field) for p in files]
+    if hostio._io() is not None:
+        # the native reader holds no GIL (gunzip + scan are ~90 % of a shard's time): threads parse while this
+        # thread brings the GPU up, and the parsed text is never pickled between processes
+        from multiprocessing.pool import ThreadPool
+        from ..minhash import Engine, padded_size
+        with ThreadPool(max(1, workers)) as pool:
+            pending = pool.map_async(_parse, tasks)
+            eng = Engine(device)
+            parsed = pending.get()
+    else:
+        pool = mp.get_context("fork").Pool(max(1, workers))       # forked before this process touches the GPU
+        try:
+            parsed = pool.map(_parse, tasks)
+        finally:
+            pool.close()
+            pool.join()
+        from ..minhash import Engine, padded_size
+        eng = Engine(device)
     total = sum(int(t.size) for *_, t, _ in parsed)
     buf = np.zeros(padded_size(total), dtype=np.uint8)
     offs, doc_file, doc_row, doc_ids, per_file, base = [np.zeros(1, np.uint64)], [], [], [], [], 0

@@ -36,11 +36,17 @@ bool read_file(const char* path, std::vector<uint8_t>& out) {
     if (!f) return false;
     uint8_t magic[2] = {0, 0};
     size_t got = fread(magic, 1, 2, f);
+    // a single-member gzip file ends with its uncompressed size mod 2^32: used only to reserve the buffer once
+    size_t isize_hint = 0;
+    uint8_t tail[4];
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b && fseek(f, -4, SEEK_END) == 0 && fread(tail, 1, 4, f) == 4)
+        isize_hint = (size_t)tail[0] | (size_t)tail[1] << 8 | (size_t)tail[2] << 16 | (size_t)tail[3] << 24;
     fclose(f);
     if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
         gzFile g = gzopen(path, "rb");
         if (!g) return false;
         gzbuffer(g, 1 << 20);
+        out.reserve(isize_hint);
         std::vector<uint8_t> buf(4 << 20);
         for (;;) {
             int n = gzread(g, buf.data(), (unsigned)buf.size());
@@ -173,8 +179,11 @@ struct Scanner {
                 continue;
             }
             if (c < 0x80) {
-                if (out) out->push_back(c);
-                p++;
+                // longest run of bytes that stand for themselves: one bulk append instead of a push_back per byte
+                const uint8_t* run = p;
+                do p++;
+                while (p < end && *p >= 0x20 && *p < 0x80 && *p != '"' && *p != '\\');
+                if (out) out->insert(out->end(), run, p);
             } else {
                 const uint8_t* s = p;
                 if (!utf8_seq()) return false;
@@ -323,12 +332,13 @@ int mdd_io_read_jsonl(const char* path, const char* content_field, const char* i
     const uint8_t* base = s->raw.data();
     const size_t n = s->raw.size();
     s->offsets.push_back(0);
+    s->text.reserve(n);  // decoded contents are never longer than the lines they come from
     std::vector<uint8_t> val, norm;
     uint64_t lineno = 0;
     size_t pos = 0;
     while (pos < n) {
-        size_t e = pos;
-        while (e < n && base[e] != '\n') e++;
+        const void* nl = memchr(base + pos, '\n', n - pos);
+        size_t e = nl ? (size_t)((const uint8_t*)nl - base) : n;
         size_t next = e < n ? e + 1 : n;
         bool blank = true;
         for (size_t i = pos; i < e; i++)
