@@ -249,6 +249,15 @@ int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
 int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                            const uint8_t* non_ascii, const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity);
 
+/* Packed corpus of selected documents: output document k = input document sel[k] (any order, repeats allowed).
+ * This is the row movement between the EN steps -- the survivors of dropDuplicates (EXD:17) and of the left_anti
+ * join (EN:149), the doc_id order paragraph dedup wants (PAR:21-26 orderBy) -- done on the packed text in HBM.
+ * out_offsets[n_sel+1] is the caller's exclusive scan of the selected lengths; document k is copied to
+ * out_text[out_offsets[k] ..) and nothing is written at or beyond out_capacity.  text and out_text must be 4-byte
+ * aligned (dword copies with a byte-aligned source); sel entries >= n_docs select nothing. */
+int mdd_gather_docs(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                    const uint64_t* sel, uint64_t n_sel, const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity);
+
 /* Measurement helper: runs `iters` iterations of a dependency-free
  * v_xor/v_add/v_lshr mix on every CU and reports the measured int32 VALU lane-op rate in
  * *tops_host (HOST double, 1e12 lane-ops/s).  Synchronous. */

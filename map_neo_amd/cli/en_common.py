@@ -27,62 +27,43 @@ def load_corpus(input_dir: str, workers: int, device: int = 0, content_field: st
     from .. import hostio
     files = hostio.list_files(input_dir)
     tasks = [(p, content_field, id_field) for p in files]
+    import torch
+    from ..minhash import Engine, padded_size
     if hostio._io() is not None:
         # the native reader holds no GIL (gunzip + scan are ~90 % of a shard's time): threads parse while this
         # thread brings the GPU up, and the parsed text is never pickled between processes
         from multiprocessing.pool import ThreadPool
-        from ..minhash import Engine, padded_size
-        with ThreadPool(max(1, workers)) as pool:
-            pending = pool.map_async(_parse, tasks)
-            eng = Engine(device)
-            parsed = pending.get()
+        pool = ThreadPool(max(1, workers))
     else:
         pool = mp.get_context("fork").Pool(max(1, workers))       # forked before this process touches the GPU
-        try:
-            parsed = pool.map(_parse, tasks)
-        finally:
-            pool.close()
-            pool.join()
-        from ..minhash import Engine, padded_size
+    try:
+        parsed = pool.imap(_parse, tasks)                         # in file order; every shard goes to HBM as it arrives
         eng = Engine(device)
-    total = sum(int(t.size) for *_, t, _ in parsed)
-    buf = np.zeros(padded_size(total), dtype=np.uint8)
-    offs, doc_file, doc_row, doc_ids, per_file, base = [np.zeros(1, np.uint64)], [], [], [], [], 0
-    for fi, (ids, line_no, cand, text, o) in enumerate(parsed):
-        buf[base: base + text.size] = text
-        offs.append(o[1:] + np.uint64(base))
-        base += int(text.size)
-        doc_file.append(np.full(len(cand), fi, dtype=np.int64))
-        doc_row.append(line_no[cand].astype(np.int64) if len(cand) else np.zeros(0, np.int64))
-        doc_ids.extend(ids[i] for i in cand.tolist())
-        per_file.append((ids, line_no, cand))
-    return {"files": files, "eng": eng, "text": eng.to_device(buf), "offs": eng.to_device(np.concatenate(offs)),
+        eng.warm_up()
+        parts, offs, doc_file, doc_row, doc_ids, per_file, base = [], [np.zeros(1, np.uint64)], [], [], [], [], 0
+        for fi, (ids, line_no, cand, text, o) in enumerate(parsed):
+            if text.size:
+                parts.append(eng.to_device(text))
+            offs.append(o[1:] + np.uint64(base))
+            base += int(text.size)
+            doc_file.append(np.full(len(cand), fi, dtype=np.int64))
+            doc_row.append(line_no[cand].astype(np.int64) if len(cand) else np.zeros(0, np.int64))
+            doc_ids.extend(ids[i] for i in cand.tolist())
+            per_file.append((ids, line_no, cand))
+    finally:
+        pool.close()
+        pool.join()
+    parts.append(torch.zeros(padded_size(base) - base, dtype=torch.uint8, device=eng.device))
+    return {"files": files, "eng": eng, "text": torch.cat(parts), "offs": eng.to_device(np.concatenate(offs)),
             "doc_file": np.concatenate(doc_file) if doc_file else np.zeros(0, np.int64),
             "doc_row": np.concatenate(doc_row) if doc_row else np.zeros(0, np.int64), "doc_ids": doc_ids,
             "rows_per_file": per_file, "workers": workers}
 
 
-def reorder_packed(text, offs, perm):
-    """Packed corpus with its documents permuted (device): document k of the result = document perm[k]"""
-    import torch
-    from ..exact import _cumsum
-    from ..minhash import padded_size
-    lens = (offs[1:] - offs[:-1])[perm]
-    new_offs = torch.zeros(perm.numel() + 1, dtype=torch.int64, device=text.device)
-    torch.cumsum(lens, 0, out=new_offs[1:])
-    total = int(new_offs[-1].item()) if perm.numel() else 0
-    out = torch.zeros(padded_size(total), dtype=torch.uint8, device=text.device)
-    if total:
-        # source byte of output byte i = i + shift(document of i); the shifts are laid down as differences at
-        # the document starts and prefix-summed (empty documents add their differences at the same position)
-        shift = offs[:-1][perm] - new_offs[:-1]
-        delta = torch.zeros(total + 1, dtype=torch.int64, device=text.device)
-        delta.index_add_(0, new_offs[:-1], torch.cat([shift[:1], shift[1:] - shift[:-1]]))
-        src = _cumsum(delta[:-1], torch.empty(total, dtype=torch.int64, device=text.device))
-        del delta
-        src += torch.arange(total, dtype=torch.int64, device=text.device)
-        out[:total] = text[src]
-    return out, new_offs
+def reorder_packed(eng, text, offs, perm):
+    """Packed corpus with its documents permuted / selected (device): document k of the result = document perm[k].
+    One pass over the selected text (mdd_gather_docs): no per-byte index tensors, so it scales with the corpus."""
+    return eng.gather_docs(text, offs, perm)
 
 
 def _write_part(task):

@@ -69,7 +69,7 @@ def run(args) -> dict:
     # 1. exact document dedup (EXD:17): first row of every content
     keep = exact.exact_document_dedup_packed(eng, text, offs)
     sel = torch.nonzero(keep).flatten()
-    text, offs = reorder_packed(text, offs, sel)
+    text, offs = reorder_packed(eng, text, offs, sel)
     ids = [ids[k] for k in sel.cpu().tolist()]
     counts["after_exact_document"] = len(ids)
     t.append(time.time())
@@ -78,13 +78,13 @@ def run(args) -> dict:
     remove_ids, _ = removed_doc_ids(eng, sig, ids, 9, 13)
     del sig
     sel = eng.to_device(np.asarray([k for k, d in enumerate(ids) if d not in remove_ids], dtype=np.int64))
-    text, offs = reorder_packed(text, offs, sel)
+    text, offs = reorder_packed(eng, text, offs, sel)
     ids = [d for d in ids if d not in remove_ids]
     counts["after_minhash"] = len(ids)
     t.append(time.time())
     # 3. paragraph dedup (PAR:15-30): documents in doc_id order
     order = sorted(range(len(ids)), key=lambda k: ids[k])
-    text, offs = reorder_packed(text, offs, eng.to_device(np.asarray(order, dtype=np.int64)))
+    text, offs = reorder_packed(eng, text, offs, eng.to_device(np.asarray(order, dtype=np.int64)))
     text, offs, docs = exact.paragraph_dedup_packed(eng, text, offs, 20)
     ids = [ids[order[d]] for d in docs.cpu().tolist()]
     counts["after_paragraph"] = len(ids)

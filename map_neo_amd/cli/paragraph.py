@@ -41,7 +41,7 @@ def run(args) -> dict:
     t1 = time.time()
     order = sorted(range(len(ids)), key=lambda k: ids[k])                  # Window.orderBy(doc_id, pos); stable
     perm = eng.to_device(np.asarray(order, dtype=np.int64))
-    text, offs = reorder_packed(c["text"], c["offs"], perm)
+    text, offs = reorder_packed(c["eng"], c["text"], c["offs"], perm)
     out_text, out_offs, docs = exact.paragraph_dedup_packed(eng, text, offs, args.min_len)
     kept_ids = [ids[order[d]] for d in docs.cpu().tolist()]
     t2 = time.time()

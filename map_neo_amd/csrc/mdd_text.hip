@@ -78,6 +78,51 @@ __global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict_
     }
 }
 
+// Output document k = input document sel[k].  One wave per output document: up to 3 head bytes bring the
+// destination to a dword boundary, the body moves aligned destination dwords assembled from two aligned source
+// dwords (v_alignbyte; four independent loads in flight), up to 3 tail bytes finish.  The source dword after a
+// document's last byte lies inside the MDD_TEXT_PAD bytes every text buffer carries.
+__global__ void __launch_bounds__(256) gather_docs_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                          const uint64_t* __restrict__ offs, uint64_t n_src,
+                                                          const uint64_t* __restrict__ sel, uint64_t n_sel,
+                                                          const uint64_t* __restrict__ out_offs, uint8_t* __restrict__ out_text,
+                                                          uint64_t out_cap) {
+    const uint32_t lane = lane_id();
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < n_sel; k += nw) {
+        const uint64_t s = sel[k];
+        if (s >= n_src) continue;
+        uint64_t b, e;
+        doc_range(offs, s, text_bytes, b, e);
+        const uint64_t o = out_offs[k];
+        if (o >= out_cap) continue;  // out_offsets are the caller's: stay inside out_text
+        uint64_t len = e - b;
+        len = len < out_cap - o ? len : out_cap - o;
+        const uint64_t head = ((4 - (o & 3)) & 3) < len ? ((4 - (o & 3)) & 3) : len;
+        if (lane < head) out_text[o + lane] = text[b + lane];
+        const uint64_t nd = (len - head) >> 2, src = b + head;
+        const uint32_t m = (uint32_t)(src & 3);
+        const uint32_t* __restrict__ sw = reinterpret_cast<const uint32_t*>(text + (src - m));
+        uint32_t* __restrict__ dw = reinterpret_cast<uint32_t*>(out_text + o + head);
+        for (uint64_t j0 = 0; j0 < nd; j0 += 256) {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t j = j0 + 64 * u + lane;
+                lo[u] = j < nd ? sw[j] : 0u;
+                hi[u] = (j < nd && m) ? sw[j + 1] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t j = j0 + 64 * u + lane;
+                if (j < nd) dw[j] = __builtin_amdgcn_alignbyte(hi[u], lo[u], m);
+            }
+        }
+        const uint64_t done = head + 4 * nd;
+        if (lane < len - done) out_text[o + done + lane] = text[b + done + lane];
+    }
+}
+
 unsigned norm_grid(const mdd_ctx* ctx, uint64_t n) {
     uint64_t blocks = (n + 3) / 4, cap = (uint64_t)ctx->cus * 64;
     return (unsigned)(blocks < cap ? blocks : cap);
@@ -105,6 +150,23 @@ extern "C" int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, uint64_
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(norm_en_kernel<true>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
                        (uint64_t*)nullptr, const_cast<uint8_t*>(non_ascii), out_offsets, out_text, out_capacity);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+extern "C" int mdd_gather_docs(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                               const uint64_t* sel, uint64_t n_sel, const uint64_t* out_offsets, uint8_t* out_text,
+                               uint64_t out_capacity) {
+    REQUIRE(ctx, "mdd_gather_docs: NULL context");
+    if (n_sel == 0) return MDD_OK;
+    REQUIRE(offsets && sel && out_offsets && (text || text_bytes == 0) && (out_text || out_capacity == 0),
+            "mdd_gather_docs: NULL buffer");
+    REQUIRE(((reinterpret_cast<uintptr_t>(text) | reinterpret_cast<uintptr_t>(out_text)) & 3u) == 0,
+            "mdd_gather_docs: text and out_text must be 4-byte aligned");
+    if (n_docs == 0 || out_capacity == 0) return MDD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(gather_docs_kernel, dim3(norm_grid(ctx, n_sel)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
+                       sel, n_sel, out_offsets, out_text, out_capacity);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mdd_substr_write": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp, _vp, _u64]),
     "mdd_normalize_en_count": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp]),
     "mdd_normalize_en_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _u64]),
+    "mdd_gather_docs": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64]),
     "mdd_exact_group": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _vp, _vp]),
     "mdd_valu_calibrate": (_int, [_vp, _int, C.POINTER(C.c_double)]),
 }

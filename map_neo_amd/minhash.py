@@ -108,6 +108,12 @@ class Engine:
     def sync(self):
         _lib.check(self.L.mdd_ctx_sync(self.ctx), "mdd_ctx_sync")
 
+    def warm_up(self):
+        """The first launch from libmdd_hip.so loads its code object (~0.1 s): do it now (one 64-element launch),
+        e.g. while host threads are still parsing shards"""
+        self.components_init(64)
+        self.sync()
+
     # ------------------------------------------------------------------ helpers
     def empty(self, n, dtype):
         return torch.empty(int(n), dtype=dtype, device=self.device)
@@ -357,6 +363,24 @@ class Engine:
         _lib.check(self.L.mdd_normalize_en_write(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(flags), _ptr(out_offs),
                                                  _ptr(out_text), total), "mdd_normalize_en_write")
         return out_text, out_offs, flags
+
+    def gather_docs(self, text: torch.Tensor, offsets: torch.Tensor, sel: torch.Tensor):
+        """Packed corpus whose document k is document sel[k] of (text, offsets); sel int64 on the device, any order,
+        repeats allowed.  Returns (out_text uint8 [padded], out_offsets int64 [len(sel)+1])."""
+        n = offsets.numel() - 1
+        sel = sel.to(device=self.device, dtype=torch.int64).contiguous()
+        m = sel.numel()
+        out_offs = torch.zeros(m + 1, dtype=torch.int64, device=self.device)
+        if m:
+            if n <= 0 or int(sel.min().item()) < 0 or int(sel.max().item()) >= n:
+                raise IndexError("gather_docs: sel outside [0, n_docs)")
+            torch.cumsum((offsets[1:] - offsets[:-1])[sel], 0, out=out_offs[1:])
+        total = int(out_offs[-1].item()) if m else 0
+        out_text = torch.zeros(padded_size(total), dtype=torch.uint8, device=self.device)
+        text_bytes = max(0, text.numel() - TEXT_PAD)
+        _lib.check(self.L.mdd_gather_docs(self.ctx, _ptr(text), text_bytes, _ptr(offsets), max(n, 0), _ptr(sel), m, _ptr(out_offs),
+                                          _ptr(out_text), total), "mdd_gather_docs")
+        return out_text, out_offs
 
     def valu_calibrate(self, iters: int = 20000) -> float:
         out = C.c_double(0.0)

@@ -53,3 +53,42 @@ def test_long_document_and_full_pipeline_equivalence(engine):
     nbuf, noffs = pack_texts([hostio.normalize_text(d) for d in docs])
     exp = RC.signatures(nbuf, noffs)
     assert (sig == exp).all()
+
+
+def test_gather_docs_matches_python(engine):
+    """mdd_gather_docs (row movement between the EN steps): every source / destination alignment, empty documents,
+    repeats, reversed order, one long document; against plain Python slicing"""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(17))
+    docs = [bytes(rng.integers(1, 255, int(n), dtype=np.uint8)) for n in
+            list(range(0, 40)) + [63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4099, 70001] + rng.integers(0, 3000, 300).tolist()]
+    buf, offs = pack_texts(docs)
+    text, o = engine.to_device(buf), engine.to_device(offs)
+    n = len(docs)
+    for sel in (np.arange(n), np.arange(n)[::-1].copy(), rng.permutation(n), rng.integers(0, n, 1000), np.array([n - 1] * 5 + [0, 0]),
+                np.zeros(0, np.int64), np.array([0])):
+        sel = sel.astype(np.int64)
+        t2, o2 = engine.gather_docs(text, o, engine.to_device(sel))
+        o2h = o2.cpu().numpy()
+        raw = t2.cpu().numpy().tobytes()
+        assert o2h.shape[0] == sel.shape[0] + 1 and o2h[0] == 0
+        assert [raw[o2h[k]:o2h[k + 1]] for k in range(sel.shape[0])] == [docs[i] for i in sel.tolist()]
+        assert not any(raw[o2h[-1]:])                                            # the padding stays zero
+    with pytest.raises(IndexError):
+        engine.gather_docs(text, o, engine.to_device(np.array([n], dtype=np.int64)))
+    with pytest.raises(IndexError):
+        engine.gather_docs(text, o, engine.to_device(np.array([-1], dtype=np.int64)))
+    # through the C ABI with a capacity smaller than the selection: nothing is written at or beyond it
+    from map_neo_amd.minhash import _ptr
+    sel = engine.to_device(np.arange(n, dtype=np.int64))
+    lens = (o[1:] - o[:-1])
+    oo = torch.zeros(n + 1, dtype=torch.int64, device=engine.device)
+    torch.cumsum(lens, 0, out=oo[1:])
+    total = int(oo[-1].item())
+    cap = total // 2 + 1
+    out = torch.full((total + 128,), 0xEE, dtype=torch.uint8, device=engine.device)
+    rc = engine.L.mdd_gather_docs(engine.ctx, _ptr(text), total, _ptr(o), n, _ptr(sel), n, _ptr(oo), _ptr(out), cap)
+    assert rc == 0
+    engine.sync()
+    outh = out.cpu().numpy()
+    assert (outh[cap:] == 0xEE).all() and outh[:cap].tobytes() == b"".join(docs)[:cap]
