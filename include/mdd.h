@@ -62,6 +62,13 @@ int mdd_ctx_sync(mdd_ctx* ctx);
  * minima are combined with atomicMin -- results are identical, only load balance changes.
  * The context owns the small segment queue (8 MiB, allocated by mdd_ctx_create). */
 int mdd_ctx_set_segment_bytes(mdd_ctx* ctx, uint32_t seg_bytes);
+/* Permute-phase filter of mdd_signatures (no counterpart in the reference; results never
+ * change, only speed).  Once a work item has hashed `n_shingles - 1` shingles, a shingle hash
+ * is first tested with the low product only (u = lo32(a*h + b + 1) + 7 > sat(min + 6) proves it
+ * cannot lower that permutation's minimum) and the full a*h+b fold runs only for hashes some
+ * permutation can still use.  0 = default (256 shingles per 64 permutations of K);
+ * 1 = filter from the first shingle; 0xFFFFFFFF = never filter.  A tuning / testing knob. */
+int mdd_ctx_set_filter_from(mdd_ctx* ctx, uint32_t n_shingles);
 
 /* Permutation table.  Replaces datasketch MinHash.__init__/_init_permutations, which the
  * reference re-runs for every document through `MinHash(num_perm=128)` (EN:62, ZH-1:28):

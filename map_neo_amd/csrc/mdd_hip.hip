@@ -218,6 +218,7 @@ struct SigArgs {
     // documents longer than seg_bytes are cut into segments of shingle START offsets; segment 0
     // belongs to the document's own wave, segments >= 1 are listed in items[] (doc << 24 | seg)
     uint32_t seg_bytes;
+    uint32_t filter_from;  // shingles of a work item permuted in full before the filter starts (0xFFFFFFFF: never)
     const uint64_t* items;
     const uint64_t* n_items;
     uint64_t max_items;
@@ -232,6 +233,9 @@ struct SigArgs {
 #ifndef MDD_WPE
 #define MDD_WPE 3
 #endif
+#ifndef MDD_FILTER_FROM  // shingles of a work item hashed in full, per 64 permutations of K, before the
+#define MDD_FILTER_FROM 256  // permute phase starts filtering (measured: 512 at K = 128, 1024 at K = 256)
+#endif
 template <int KPL, bool DUMP>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(MDD_WPE, 8))) sig_kernel(SigArgs A) {
     __shared__ WaveLds lds_all[WAVES];
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const uint8_t* text = A.text;
 
     // ---- permutation constants: lane owns perms q*64 + lane (loaded once per wave)
-    uint32_t alo[KPL], ahi[KPL], blo[KPL], bhi[KPL];
+    uint32_t alo[KPL], ahi[KPL], blo[KPL], bhi[KPL], bl8[KPL];
     if (!DUMP) {
 #pragma unroll
         for (int q = 0; q < KPL; q++) {
@@ -258,6 +262,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             ahi[q] = (uint32_t)(av >> 32);
             blo[q] = (uint32_t)bv;
             bhi[q] = (uint32_t)(bv >> 32);
+            bl8[q] = blo[q] + 8u;  // lo32(b + 1) + 7, the filter's addend
         }
     }
 
@@ -346,22 +351,82 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         // fast form: t' = a*h + (b+1) mod 2^64 ; s = lo32(t') + (t' >> 61).
                         // If s > 8 then s - 1 is exactly ((a*h+b) mod 2^64) mod (2^61-1) & 0xFFFFFFFF
                         // (proof in DESIGN.md); a minimum <= 8 sends the document to the exact pass.
-                        for (uint32_t i = 0; i < n4; i++) {
-                            uint4 hv = hb4[i];
-                            uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
+                        auto full = [&](uint32_t h) {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
+                            for (int q = 0; q < KPL; q++) {
+                                uint64_t b1 = (((uint64_t)bhi[q] << 32) | blo[q]) + 1ull;
+                                uint64_t t = (uint64_t)alo[q] * h + b1;
+                                // hipcc fuses this into a second v_mad_u64_u32 (+ v_mov).  Measured
+                                // alternatives, both slower: v_mul_lo_u32 + v_add_u32 (-7 %), and
+                                // pre-adding a_hi*h into the high half of the first mad's addend
+                                // (hipcc turns it into mad + mov + v_lshl_add_u64).
+                                uint32_t thi = (uint32_t)(t >> 32) + ahi[q] * h;
+                                uint32_t sv = (uint32_t)t + (thi >> 29);
+                                m[q] = sv < m[q] ? sv : m[q];
+                            }
+                        };
+                        if (n_done < A.filter_from) {
+                            for (uint32_t i = 0; i < n4; i++) {
+                                uint4 hv = hb4[i];
+                                full(hv.x);
+                                full(hv.y);
+                                full(hv.z);
+                                full(hv.w);
+                            }
+                        } else {
+                            // Filter (pays once the minima are low, i.e. after filter_from shingles of this
+                            // work item): s = lo32(t') + c with c = t' >> 61 in [0, 7], and lo32(t') needs
+                            // only the low product.  With u = lo32(t') + 7 (mod 2^32):
+                            // lo32(t') in [m, 2^32-8] <=> u > sat(m + 6), and then s >= m with no wrap, so
+                            // the hash cannot lower this permutation's minimum (a wrapping lo32(t') gives
+                            // u <= 6 and is never skipped).  After n shingles all but ~K/n of the hashes are
+                            // useless to every lane and skip the high half, the fold and the min: a group
+                            // of G hashes is tested with one v_min3 tree and one v_cmp per permutation
+                            // (lane mask straight from v_cmp, 37 = unsigned <=); only a flagged group
+                            // is tested hash by hash, against the thresholds at the group's start (a
+                            // minimum lowered inside the group only makes a later test conservative).
+                            uint32_t g[KPL];
+#pragma unroll
+                            for (int q = 0; q < KPL; q++) g[q] = (m[q] < 0xFFFFFFF9u ? m[q] : 0xFFFFFFF9u) + 6u;
+                            constexpr int G = KPL <= 2 ? 8 : 4;      // hashes per filter group (measured best)
+                            const uint32_t ng = (n4 * 4u + G - 1) / G;  // all 64 words of hbuf are written: an over-read stays in range
+                            for (uint32_t i = 0; i < ng; i++) {
+                                uint32_t hh[G];
+#pragma unroll
+                                for (int v = 0; v < G / 4; v++) {
+                                    uint4 hv = hb4[i * (G / 4) + v];
+                                    hh[4 * v] = hv.x;
+                                    hh[4 * v + 1] = hv.y;
+                                    hh[4 * v + 2] = hv.z;
+                                    hh[4 * v + 3] = hv.w;
+                                }
+                                uint32_t u[G][KPL];
+#pragma unroll
+                                for (int e = 0; e < G; e++)
+#pragma unroll
+                                    for (int q = 0; q < KPL; q++) u[e][q] = alo[q] * hh[e] + bl8[q];
+                                uint64_t any = 0ull;
 #pragma unroll
                                 for (int q = 0; q < KPL; q++) {
-                                    uint64_t b1 = (((uint64_t)bhi[q] << 32) | blo[q]) + 1ull;
-                                    uint64_t t = (uint64_t)alo[q] * hh[e] + b1;
-                                    // hipcc fuses this into a second v_mad_u64_u32 (+ v_mov).  Measured
-                                    // alternatives, both slower: v_mul_lo_u32 + v_add_u32 (-7 %), and
-                                    // pre-adding a_hi*h into the high half of the first mad's addend
-                                    // (hipcc turns it into mad + mov + v_lshl_add_u64).
-                                    uint32_t thi = (uint32_t)(t >> 32) + ahi[q] * hh[e];
-                                    uint32_t sv = (uint32_t)t + (thi >> 29);
-                                    m[q] = sv < m[q] ? sv : m[q];
+                                    uint32_t mn = u[0][q];
+#pragma unroll
+                                    for (int e = 1; e < G; e++) mn = u[e][q] < mn ? u[e][q] : mn;
+                                    any |= __builtin_amdgcn_uicmp(mn, g[q], 37);
+                                }
+                                if (any == 0ull) continue;  // the usual case: no lane can use any hash of the group
+                                uint64_t nb[G];
+#pragma unroll
+                                for (int e = 0; e < G; e++) {
+                                    nb[e] = 0ull;
+#pragma unroll
+                                    for (int q = 0; q < KPL; q++) nb[e] |= __builtin_amdgcn_uicmp(u[e][q], g[q], 37);
+                                }
+#pragma unroll
+                                for (int e = 0; e < G; e++) {
+                                    if (nb[e] == 0ull) continue;
+                                    full(hh[e]);
+#pragma unroll
+                                    for (int q = 0; q < KPL; q++) g[q] = (m[q] < 0xFFFFFFF9u ? m[q] : 0xFFFFFFF9u) + 6u;
                                 }
                             }
                         }
@@ -735,6 +800,7 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     c->stream = (hipStream_t)hip_stream;
     c->owns_stream = false;
     c->seg_bytes = SEG_BYTES_DEFAULT;
+    c->filter_from = 0;
     c->seg_items = nullptr;
     hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 2) * sizeof(uint64_t));
     if (me != hipSuccess) {
@@ -764,6 +830,12 @@ int mdd_ctx_set_segment_bytes(mdd_ctx* ctx, uint32_t seg_bytes) {
     if (seg_bytes == 0) seg_bytes = SEG_BYTES_DEFAULT;
     REQUIRE(seg_bytes >= 256 && seg_bytes % 256 == 0, "mdd_ctx_set_segment_bytes: %u is not a positive multiple of 256", seg_bytes);
     ctx->seg_bytes = seg_bytes;
+    return MDD_OK;
+}
+
+int mdd_ctx_set_filter_from(mdd_ctx* ctx, uint32_t n_shingles) {
+    REQUIRE(ctx != nullptr, "mdd_ctx_set_filter_from: ctx is NULL");
+    ctx->filter_from = n_shingles;
     return MDD_OK;
 }
 
@@ -808,6 +880,8 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
     uint64_t max_items = text_bytes / seg;  // sum over docs of (ceil(len/seg) - 1) <= text_bytes / seg
     if (max_items > SEG_ITEM_CAP) max_items = SEG_ITEM_CAP;
     A.seg_bytes = (uint32_t)seg;
+    A.filter_from = ctx->filter_from ? (ctx->filter_from == 0xFFFFFFFFu ? 0xFFFFFFFFu : ctx->filter_from - 1u)
+                                     : (uint32_t)MDD_FILTER_FROM * (uint32_t)((K + 63) / 64);
     A.items = ctx->seg_items;
     A.n_items = ctx->seg_n_items;
     A.max_items = max_items;

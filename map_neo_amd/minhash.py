@@ -105,6 +105,11 @@ class Engine:
         """Documents longer than this are split across waves (0 = library default)."""
         _lib.check(self.L.mdd_ctx_set_segment_bytes(self.ctx, int(seg_bytes)), "mdd_ctx_set_segment_bytes")
 
+    def set_filter_from(self, n_shingles: int = 0):
+        """Permute-phase filter of the signature kernel: 0 = default, 1 = from the first shingle,
+        0xFFFFFFFF = never.  Results are identical for every setting."""
+        _lib.check(self.L.mdd_ctx_set_filter_from(self.ctx, int(n_shingles)), "mdd_ctx_set_filter_from")
+
     def sync(self):
         _lib.check(self.L.mdd_ctx_sync(self.ctx), "mdd_ctx_sync")
 
