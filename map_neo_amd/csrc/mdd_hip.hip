@@ -230,9 +230,9 @@ struct SigArgs {
     uint64_t* dump_n;
 };
 
-#ifndef MDD_WPE
-#define MDD_WPE 3
-#endif
+#ifndef MDD_WPE  // waves per SIMD the register budget is set for.  The filtered permute phase is a chain of
+#define MDD_WPE 4  // dependent mad -> min -> cmp -> branch, so a 4th wave pays (+5 % ASCII, +9 % word 5-grams)
+#endif             // although 4-12 VGPRs of the non-ASCII boundary scan then live in scratch; 5 and 6 are slower
 #ifndef MDD_FILTER_FROM  // shingles of a work item hashed in full, per 64 permutations of K, before the
 #define MDD_FILTER_FROM 256  // permute phase starts filtering (measured: 512 at K = 128, 1024 at K = 256)
 #endif

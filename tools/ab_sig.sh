@@ -1,7 +1,6 @@
-# development A/B of sig_kernel's filter variants: binaries built from tools/sig_bench.hip with
-# -DMDD_FG=<hashes per group> -DMDD_FV=<compare style> (off = -DMDD_FILTER_FROM=0xFFFFFFFFu)
+# development A/B of sig_kernel: waves per SIMD (binaries built from tools/sig_bench.hip with -DMDD_WPE=n)
 set -e
-for args in "400000 2048 60 128 0" "400000 2048 60 256 0" "40000 20480 60 128 0" "4000 204800 100 128 0"; do
+for args in "400000 2048 60 128 0" "400000 2048 60 256 0" "40000 20480 60 128 0" "400000 2048 60 128 1" "400000 2048 60 128 0 1 5" "400000 2048 60 128 0 0 20" "400000 300 60 128 0"; do
   echo "== $args"
-  for m in off g4v2 g8v2 g8t512 g8t2048 g16t1024 g16t2048; do echo -n "$m "; timeout -k 10 60 ./build/sig_bench_$m $args | cut -c95-200; done
+  for w in 3 4 5 6; do echo -n "wpe=$w "; timeout -k 10 60 ./build/sig_bench_w$w $args | cut -c95-200; done
 done

@@ -1,7 +1,7 @@
 // Standalone timing harness for sig_kernel (development tool; bench.py is the judged bench).
 // Includes the library source directly so kernel variants can be toggled with -D macros.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o build/sig_bench tools/sig_bench.hip
-//   ./build/sig_bench [n_docs] [mean_bytes] [sigma_x100] [K] [lang: 0 ascii, 1 cjk]
+//   ./build/sig_bench [n_docs] [mean_bytes] [sigma_x100] [K] [lang: 0 ascii, 1 cjk] [unit] [width] [seg_bytes] [filter_from]
 #include "../map_neo_amd/csrc/mdd_hip.hip"
 
 #include <cmath>
@@ -19,6 +19,8 @@ int main(int argc, char** argv) {
     int lang = argc > 5 ? atoi(argv[5]) : 0;
     int unit = argc > 6 ? atoi(argv[6]) : 0;
     int width = argc > 7 ? atoi(argv[7]) : 13;
+    uint32_t seg_bytes = argc > 8 ? (uint32_t)strtoul(argv[8], 0, 10) : 0;
+    uint32_t filter_from = argc > 9 ? (uint32_t)strtoul(argv[9], 0, 10) : 0;
     std::mt19937_64 rng(12345);
     std::lognormal_distribution<double> ln(std::log(mean) - 0.5 * sigma * sigma, sigma);
     std::vector<uint64_t> offs(n + 1, 0);
@@ -64,6 +66,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(da, a.data(), K * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), K * 8, hipMemcpyHostToDevice));
     mdd_ctx* ctx;
     if (mdd_ctx_create(0, nullptr, &ctx)) { fprintf(stderr, "%s\n", mdd_last_error()); return 1; }
+    if (mdd_ctx_set_segment_bytes(ctx, seg_bytes) || mdd_ctx_set_filter_from(ctx, filter_from)) { fprintf(stderr, "%s\n", mdd_last_error()); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
