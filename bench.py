@@ -28,9 +28,10 @@ WIDTH, K, BANDS, ROWS = 13, 128, 9, 13
 OPS_PER_SHINGLE = lambda k: 958 + 14 * k          # SURVEY.md 8(d) algorithmic int32 ops per shingle
 PEAK_VALU_TOPS = 78.6                             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: one simple int32 op per lane per issue slot
 #                                                   (= half of the guide's 157.3 TFLOPS FP32 vector peak, which counts FMA as 2)
-# Minimum VALU issue time of the shipped instruction stream, in 2-cycle issue slots per
-# shingle (DESIGN.md "Cost model"): SHA-1 single block + message assembly, and per
-# permutation 2 x v_mad_u64_u32 (2.25 each) + v_mov + v_lshrrev + v_add + half a v_min3.
+# Minimum VALU issue time of the instruction stream that evaluates every (hash, permutation)
+# pair in full, in 2-cycle issue slots per shingle (DESIGN.md "Cost model"): SHA-1 single block
+# + message assembly, and per permutation 2 x v_mad_u64_u32 (2.25 each) + v_mov + v_lshrrev +
+# v_add + half a v_min3.  The shipped kernel filters most pairs out after the first shingles.
 ISSUE_SLOTS_PER_SHINGLE = lambda k: 1150 + 8.5 * k
 
 
@@ -369,10 +370,10 @@ def main():
 
     if rank == 0:
         # HBM bytes per sig_kernel launch from the PMC passes of this same command (tools/pmc_bench.sh ->
-        # profiles/r1_pmc_bench/summary.json, FETCH_SIZE corrected x2 as calibrated); null if the workload differs
+        # profiles/r1m_pmc_bench/summary.json, FETCH_SIZE corrected x2 as calibrated); null if the workload differs
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_bench", "summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1m_pmc_bench", "summary.json")))
             if pm["workload"]["text_bytes_per_gpu"] == text_bytes and pm["workload"]["docs_per_gpu"] == n_local:
                 k = pm["kernels"]["sig_kernel<2, false>"]
                 traffic = k["fetch_bytes"] + k["write_bytes"]
@@ -421,12 +422,15 @@ def main():
                                        "note": "the same launch priced against HBM: <1 % of 8 TB/s, i.e. the kernel is "
                                                "nowhere near memory-bound; ~2 750 integer ops per text byte put it on the VALU"}
                                       if sig_ms else None),
-                         "issue_slot_utilisation": (n_shingles * ISSUE_SLOTS_PER_SHINGLE(K) / 78.6e12 / (sig_ms * 1e-3))
+                         "unfiltered_stream_ratio": (n_shingles * ISSUE_SLOTS_PER_SHINGLE(K) / 78.6e12 / (sig_ms * 1e-3))
                          if sig_ms else None,
                          "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz simple int32 lane-ops; frac can exceed 1 because "
-                                 "v_mad_u64_u32 / v_add3 / v_bitop3 retire 2-5 of SURVEY 8(d)'s elementary ops per issue; "
-                                 "issue_slot_utilisation = modelled minimum issue time / measured time (DESIGN.md); "
-                                 "traffic from profiles/r1_pmc_bench/summary.json"},
+                                 "v_mad_u64_u32 / v_add3 / v_bitop3 retire 2-5 of SURVEY 8(d)'s elementary ops per issue and "
+                                 "because the permute-phase filter proves most (hash, permutation) pairs irrelevant from the "
+                                 "low product alone; unfiltered_stream_ratio = minimum VALU issue time of the stream that "
+                                 "evaluates every pair in full (1150 + 8.5 K issue slots per shingle, DESIGN.md 4.1) / measured "
+                                 "time: 0.97 before the filter existed, > 1 now = issue work the filter removed; measured VALU "
+                                 "instruction counts: profiles/r1m_pmc_sig; traffic from profiles/r1m_pmc_bench/summary.json"},
         }
         # HBM-bound stages: SURVEY 8(d)'s algorithmic bytes per document against the 8 TB/s peak
         hbm_alg = {"band_keys": 4 * K + BANDS * 20, "bucket_edges": 2 * BANDS * 20, "components": BANDS * 8 + 4}
