@@ -118,6 +118,7 @@ __device__ __forceinline__ void sha1_compress(uint32_t (&st)[5], uint32_t (&w)[1
             f = __builtin_amdgcn_bitop3_b32(b, c, d, 0x96);
             k = 0xCA62C1D6u;
         }
+        // (moving e + k + w off the a -> rol -> add chain, forced with an asm barrier, measured -2 %: the phase is issue-bound)
         uint32_t tmp = rol(a, 5) + f + e + k + w[t & 15];
         e = d;
         d = c;

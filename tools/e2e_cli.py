@@ -13,11 +13,62 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def zh(n, shards, workers):
+    """The ZH path end to end on plain jsonl files (field `text`, doc identity file@line): the five reference
+    commands ZH-1..ZH-5 through their artifacts on disk, then the fused command; both must write the same files."""
+    import filecmp
+    from map_neo_amd import corpus
+    from map_neo_amd.cli import (generate_connected_components, generate_dup_line_id_for_each_file, generate_dup_pairs,
+                                 generate_minhash, remove_dup, zh_dedup)
+    spec = corpus.CorpusSpec(n, 2048, seed=9, lang="zh")
+    text, offs = corpus.generate(spec)
+    tb = text.numpy().tobytes()
+    o = offs.numpy()
+    root = tempfile.mkdtemp(prefix="mdd_e2e_zh_")
+    inp = os.path.join(root, "in")
+    os.makedirs(inp)
+    per = (n + shards - 1) // shards
+    for s in range(shards):
+        with open(os.path.join(inp, f"part-{s:04d}.jsonl"), "w", encoding="utf8") as f:
+            for i in range(s * per, min(n, (s + 1) * per)):
+                f.write(json.dumps({"text": tb[o[i]:o[i + 1]].decode(), "url": "x"}, ensure_ascii=False) + "\n")
+    M, P, C, D, O, O2 = (os.path.join(root, x) for x in ("minhash", "pairs", "cc.pkl", "lineids", "out", "out_fused"))
+    steps = {}
+
+    def timed(name, fn, argv):
+        t0 = time.time()
+        fn(argv)
+        steps[name] = time.time() - t0
+
+    t_all = time.time()
+    timed("generate_minhash", generate_minhash.main, ["--input_dir", inp, "--output_dir", M, "--workers", str(workers)])
+    timed("generate_dup_pairs", generate_dup_pairs.main, ["--input_dir", M, "--output_dir", P])
+    timed("generate_connected_components", generate_connected_components.main, ["--input_dir", P, "--output_file", C])
+    timed("generate_dup_line_id_for_each_file", generate_dup_line_id_for_each_file.main, ["--input_file", C, "--output_dir", D])
+    timed("remove_dup", remove_dup.main, ["--input_dir", inp, "--output_dir", O, "--dup_line_id_dir", D, "--workers", str(workers)])
+    wall5 = time.time() - t_all
+    t0 = time.time()
+    zh_dedup.main(["--input_dir", inp, "--output_dir", O2])
+    wall_fused = time.time() - t0
+    names = sorted(os.listdir(inp))
+    same = all(filecmp.cmp(os.path.join(O, f), os.path.join(O2, f), shallow=False) for f in names)
+    kept = sum(1 for f in names for _ in open(os.path.join(O2, f), "rb"))
+    print(json.dumps({"mode": "zh", "docs": n, "text_bytes": int(o[-1]), "shards": shards, "workers": workers,
+                      "five_commands_wall_s": wall5, "five_commands_docs_per_s": n / wall5, "steps_s": steps,
+                      "fused_wall_s": wall_fused, "fused_docs_per_s": n / wall_fused,
+                      "outputs_identical": same, "docs_kept": kept, "docs_removed": n - kept}))
+    shutil.rmtree(root, ignore_errors=True)
+    assert same, "five-step and fused ZH outputs differ"
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
     shards = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-    mode = sys.argv[4] if len(sys.argv) > 4 else "minhash"      # "minhash": the EN drop-in; "pipeline": en_dedup_pipeline
+    mode = sys.argv[4] if len(sys.argv) > 4 else "minhash"      # "minhash": the EN drop-in; "pipeline": en_dedup_pipeline;
+    #                                                               "zh": the five ZH commands, then the fused zh_dedup
+    if mode == "zh":
+        return zh(n, shards, workers)
     from map_neo_amd import corpus
     spec = corpus.CorpusSpec(n, 2048, seed=7, lang="en")
     text, offs = corpus.generate(spec)
