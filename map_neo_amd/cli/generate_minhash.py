@@ -37,10 +37,11 @@ def process_dir(args):
     os.makedirs(args.output_dir, exist_ok=True)
     for band in range(args.bands):
         os.makedirs(os.path.join(args.output_dir, str(band)), exist_ok=True)
-    for path in hostio.list_files(args.input_dir):
-        name = os.path.basename(path)
+    files = hostio.list_files(args.input_dir)
+    # shards are parsed on threads ahead of the device; --workers (the reference's pool size, default 42) is capped
+    for fi, line_no, text, offs in Z.iter_shards(files, args.content_field_name, min(16, args.workers)):   # no normalisation in the ZH path (ZH-1:46)
+        name = os.path.basename(files[fi])
         print(f"process file {name}")
-        line_no, text, offs = Z.read_jsonl_texts(path, args.content_field_name)     # no normalisation in the ZH path (ZH-1:46)
         buf = np.zeros(padded_size(text.size), dtype=np.uint8)
         buf[: text.size] = text
         sig = as_u32(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,

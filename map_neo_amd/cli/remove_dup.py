@@ -23,10 +23,7 @@ def build_parser():
 
 def remove_dup(file_path, dup_line_id_path, output_path):
     drop = Z.read_own_pickle(dup_line_id_path) if os.path.exists(dup_line_id_path) else set()
-    with open(file_path, "rb") as f, open(output_path, "wb") as fw:
-        for idx, line in enumerate(f):
-            if idx not in drop:
-                fw.write(line)
+    Z.copy_without_lines(file_path, output_path, drop)
 
 
 def remove_dup_in_dir(args):

@@ -35,6 +35,22 @@ def read_jsonl_texts(path: str, field: str):
     return r["line_no"][r["cand"]], r["text"], r["offsets"]
 
 
+def iter_shards(files, field: str, workers: int):
+    """read_jsonl_texts for every file, in file order, parsed on `workers` threads (the native reader holds no GIL) with
+    at most 2 x workers parsed shards waiting for the consumer: parsing runs ahead of the device, host memory stays bounded."""
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, int(workers or 1))
+    ahead = 2 * workers
+    with ThreadPoolExecutor(workers) as pool:
+        pending = [pool.submit(read_jsonl_texts, p, field) for p in files[:ahead]]
+        for fi in range(len(files)):
+            res = pending[fi].result()
+            pending[fi] = None
+            if fi + ahead < len(files):
+                pending.append(pool.submit(read_jsonl_texts, files[fi + ahead], field))
+            yield (fi,) + tuple(res)
+
+
 def band_key_bytes(sig_u32: np.ndarray, band: int, rows: int) -> List[bytes]:
     """_H (ZH-1:20-21): 8-byte big-endian serialisation of hashvalues[band*r:(band+1)*r]."""
     blk = np.ascontiguousarray(sig_u32[:, band * rows:(band + 1) * rows]).astype(">u8")
@@ -48,6 +64,28 @@ def key_bytes_to_tuples(keys: List[bytes], rows: int) -> np.ndarray:
     if (arr >> np.uint64(32)).any():
         raise ValueError("band key holds a value >= 2^32: not a MinHash band artifact")
     return arr.astype(np.uint32)
+
+
+def copy_without_lines(src: str, dst: str, drop) -> None:
+    """ZH-5:7-13: copy `src` to `dst` byte for byte without the lines whose index is in `drop`.
+    Line i = data[start[i]:start[i+1]] (a last line without "\n" counts, as in `for line in f`); the kept text is
+    written as the runs between dropped lines: O(dropped lines) Python steps instead of one per line, so threads
+    copying different files do not queue on the interpreter lock."""
+    with open(src, "rb") as f:
+        data = f.read()
+    with open(dst, "wb") as fw:
+        if not drop:
+            fw.write(data)
+            return
+        nl = np.flatnonzero(np.frombuffer(data, dtype=np.uint8) == 10)
+        start = np.concatenate(([0], nl + 1, [len(data)])) if (len(data) and data[-1] != 10) else np.concatenate(([0], nl + 1))
+        n_lines = len(start) - 1
+        mv = memoryview(data)
+        pos = 0
+        for d in sorted(x for x in drop if 0 <= x < n_lines):
+            fw.write(mv[pos:int(start[d])])
+            pos = int(start[d + 1])
+        fw.write(mv[pos:])
 
 
 def write_pickle(path: str, obj) -> None:

@@ -29,7 +29,21 @@ def build_parser():
     p.add_argument("--rows", type=int, default=Z.ROWS)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1), help="threads that parse / rewrite shards")
     return p
+
+
+class _Ids:
+    """(file name, line number) of document k without building a tuple per document."""
+
+    def __init__(self, names, file_of, line_of):
+        self.names, self.file_of, self.line_of = names, file_of, line_of
+
+    def __len__(self):
+        return int(self.file_of.shape[0])
+
+    def __getitem__(self, k):
+        return self.names[int(self.file_of[k])], int(self.line_of[k])
 
 
 def run(args):
@@ -38,32 +52,43 @@ def run(args):
     from ..minhash import Engine, as_u32, padded_size
     files = hostio.list_files(args.input_dir)
     import torch
-    eng = Engine(args.device)
-    ids, sigs = [], []
-    for path in files:                                   # one shard at a time: signatures stay in HBM, text does not
-        name = os.path.basename(path)
-        line_no, text, offs = Z.read_jsonl_texts(path, args.content_field_name)
-        ids.extend((name, int(i)) for i in line_no.tolist())
-        if len(line_no):
-            buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-            buf[: text.size] = text
-            sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
-                                       args.ngram_unit, args.seed, text_bytes=int(text.size)))
+    from concurrent.futures import ThreadPoolExecutor
+    names = [os.path.basename(p) for p in files]
+    # Shards are parsed on threads (the native reader holds no GIL) and consumed in file order, so parsing runs ahead
+    # of the device; one shard's text is in HBM at a time, the signatures of all of them stay there.
+    file_of, line_of, sigs = [], [], []
+    eng = None
+    for fi, line_no, text, offs in Z.iter_shards(files, args.content_field_name, args.workers):
+        if eng is None:
+            eng = Engine(args.device)                    # comes up while the next shards are being parsed
+        if not len(line_no):
+            continue
+        file_of.append(np.full(len(line_no), fi, dtype=np.int64))
+        line_of.append(line_no.astype(np.int64))
+        buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+        buf[: text.size] = text
+        sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                                   args.ngram_unit, args.seed, text_bytes=int(text.size)))
+    if eng is None:
+        eng = Engine(args.device)
+    file_of = np.concatenate(file_of) if file_of else np.zeros(0, np.int64)
+    line_of = np.concatenate(line_of) if line_of else np.zeros(0, np.int64)
+    ids = _Ids(names, file_of, line_of)
     sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
     out = cluster_local(eng, sig, args.bands, args.rows)
     labels = as_u32(out["labels"])
     removed = labels != np.arange(len(ids), dtype=np.uint32)
-    drop = {}
-    for k in np.flatnonzero(removed).tolist():
-        drop.setdefault(ids[k][0], set()).add(ids[k][1])
+    drop = [set() for _ in files]                        # per input file: line numbers to leave out (ZH-4:15-22)
+    rk = np.flatnonzero(removed)
+    for fi, ln in zip(file_of[rk].tolist(), line_of[rk].tolist()):
+        drop[fi].add(ln)
     os.makedirs(args.output_dir, exist_ok=True)
-    for path in files:
-        name = os.path.basename(path)
-        d = drop.get(name, set())
-        with open(path, "rb") as f, open(os.path.join(args.output_dir, name), "wb") as fw:
-            for idx, line in enumerate(f):
-                if idx not in d:
-                    fw.write(line)
+
+    def copy_kept(k):                                    # ZH-5:7-13; files without duplicates are copied unchanged
+        Z.copy_without_lines(files[k], os.path.join(args.output_dir, names[k]), drop[k])
+
+    with ThreadPoolExecutor(max(1, args.workers)) as pool:
+        list(pool.map(copy_kept, range(len(files))))
     n_comp = int((labels == np.arange(len(ids))).sum())
     print("number of connected components:", n_comp)
     print("number of duplicate documents that will be removed:", int(removed.sum()))

@@ -74,3 +74,24 @@ def test_band_key_roundtrip():
         keys = Z.band_key_bytes(sig, band, 13)
         assert keys[0] == R.band_keys(sig[0].astype(np.uint64), 9, 13)[band]      # == _H(...) of ZH-1:32
         assert (Z.key_bytes_to_tuples(keys, 13) == sig[:, band * 13:(band + 1) * 13]).all()
+
+
+def test_copy_without_lines_equals_line_loop(tmp_path):
+    """ZH-5 line copy as runs between dropped lines == the reference's per-line loop, incl. empty files,
+    a last line without newline, empty lines, indices past the end"""
+    import io
+    import random
+    from map_neo_amd.cli import zh_common as Z
+    rnd = random.Random(3)
+    cases = [b"", b"\n", b"a", b"a\n", b"a\nb", b"a\nb\n", b"\n\n\n", b"a\n\nb\n\n", b"x" * 5 + b"\n" + b"y\n" * 7 + b"z",
+             "".join(f'{{"text": "行{i}"}}\n' for i in range(40)).encode()]
+    for data in cases:
+        src = tmp_path / "src.jsonl"
+        src.write_bytes(data)
+        n = data.count(b"\n") + 3
+        for _ in range(30):
+            drop = {rnd.randrange(n) for _ in range(rnd.randrange(5))}
+            exp = b"".join(line for i, line in enumerate(io.BytesIO(data)) if i not in drop)
+            dst = tmp_path / "dst.jsonl"
+            Z.copy_without_lines(str(src), str(dst), drop)
+            assert dst.read_bytes() == exp, (data, drop)
