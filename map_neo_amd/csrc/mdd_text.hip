@@ -78,6 +78,89 @@ __global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict_
     }
 }
 
+// Count pass, dword per lane (text 4-byte aligned): a lane owns 4 consecutive bytes, a wave step covers 256.
+// The byte classes come from SWAR range tests on the whole dword (bytes are < 0x80 in every document that
+// survives, so x + (128 - lo) and x + (127 - hi) never carry into the neighbour byte; bit 7 of a byte then
+// says x >= lo resp. x > hi).  Inside the lane the "previous kept byte is whitespace" / "a word was seen"
+// state runs over the 4 bytes; between lanes it comes from 3 ballots (lane has a kept byte, its last kept
+// byte is whitespace, lane has a non-whitespace byte) instead of 12 for the same 256 bytes.  Per-lane counts
+// are summed once per document.
+__device__ __forceinline__ uint32_t swar_in_range(uint32_t x7, uint32_t lo, uint32_t hi) {  // bit 7 of each byte: lo <= byte <= hi
+    return (x7 + (128u - lo) * 0x01010101u) & ~(x7 + (127u - hi) * 0x01010101u) & 0x80808080u;
+}
+
+__global__ void __launch_bounds__(256) norm_en_count4_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                             const uint64_t* __restrict__ offs, uint64_t n, uint64_t* out_len,
+                                                             uint8_t* non_ascii) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;  // lanes below this one
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        const uint64_t w0 = b >> 2, w1 = (e + 3) >> 2;  // dwords that hold the document (the last one lies inside the text's padding)
+        uint32_t cnt = 0;
+        bool carry_ws = false, carry_seen = false, bad = false;  // wave-uniform carries between steps
+        for (uint64_t wi = w0; wi < w1 && !bad; wi += 128) {
+            uint32_t ww[2];  // two independent loads in flight
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                ww[j] = (b < e && i < w1) ? tw[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                const uint64_t p = i << 2;  // position of the dword's byte 0
+                // bytes of the dword that belong to the document, as bit 7 of each byte
+                uint32_t in = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (i < w1 && p + k >= b && p + k < e) in |= 0x80u << (8 * k);
+                const uint32_t w = ww[j];
+                if (__ballot((w & in) != 0u)) {  // a byte >= 0x80: the document goes to the Python steps
+                    bad = true;
+                    break;
+                }
+                const uint32_t x = w & 0x7F7F7F7Fu;
+                const uint32_t punct = swar_in_range(x, 33, 47) | swar_in_range(x, 58, 64) | swar_in_range(x, 91, 96) |
+                                       swar_in_range(x, 123, 126);
+                const uint32_t space = swar_in_range(x, 9, 13) | swar_in_range(x, 28, 32);
+                const uint32_t K = in & ~punct, W = K & space, N = K & ~W;
+                // lane summary for the cross-lane state
+                const bool has_k = K != 0u, has_n = N != 0u;
+                const uint32_t last_k = K ? 31u - (uint32_t)__builtin_clz(K) : 0u;  // bit index of the last kept byte's flag
+                const bool last_ws = has_k && ((W >> last_k) & 1u);
+                const uint64_t BK = __ballot(has_k), BW = __ballot(last_ws), BN = __ballot(has_n);
+                const uint64_t pk = BK & lt;
+                bool pw = pk ? ((BW >> (63 - __builtin_clzll(pk))) & 1) : carry_ws;  // previous kept byte is whitespace
+                bool sn = carry_seen || (BN & lt);                                      // a non-whitespace byte was seen
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t f = 0x80u << (8 * k);
+                    if (N & f) {
+                        cnt += 1u + ((pw && sn) ? 1u : 0u);  // the byte, and the single space before it
+                        sn = true;
+                        pw = false;
+                    } else if (W & f) {
+                        pw = true;
+                    }
+                }
+                if (BK) carry_ws = (BW >> (63 - __builtin_clzll(BK))) & 1;
+                carry_seen = carry_seen || BN;
+            }
+        }
+        uint32_t tot = cnt;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+        if (lane == 0) {
+            out_len[d] = bad ? 0 : tot;
+            non_ascii[d] = bad;
+        }
+    }
+}
+
 // Output document k = input document sel[k].  One wave per output document: up to 3 head bytes bring the
 // destination to a dword boundary, the body moves aligned destination dwords assembled from two aligned source
 // dwords (v_alignbyte; four independent loads in flight), up to 3 tail bytes finish.  The source dword after a
@@ -136,8 +219,12 @@ extern "C" int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, uint64_
     if (n_docs == 0) return MDD_OK;
     REQUIRE(text && offsets && out_len && non_ascii, "mdd_normalize_en_count: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(norm_en_kernel<false>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
-                       out_len, non_ascii, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
+    if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)  // the usual case (device allocations are aligned): dword per lane
+        hipLaunchKernelGGL(norm_en_count4_kernel, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
+                           out_len, non_ascii);
+    else
+        hipLaunchKernelGGL(norm_en_kernel<false>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, out_len, non_ascii, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
