@@ -56,6 +56,77 @@ __global__ void __launch_bounds__(256) para_scan_kernel(const uint8_t* __restric
     }
 }
 
+// The same scan with a dword per lane (text 4-byte aligned): a wave step covers 256 bytes.  Newline bytes
+// are found with an exact SWAR zero-byte test on w ^ 0x0A0A0A0A; a lane holds 0..4 of them, so the rank of
+// a lane's first newline is a prefix sum over 3-bit counts = 3 ballots (UNITS) or nothing at all (count:
+// per-lane sums, added up once per document).
+template <bool UNITS>
+__global__ void __launch_bounds__(256) para_scan4_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                         const uint64_t* __restrict__ offs, uint64_t n, uint64_t* units_per_doc,
+                                                         const uint64_t* __restrict__ unit_base, uint64_t n_units, uint64_t* ubeg,
+                                                         uint64_t* uend) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        const uint64_t w0 = b >> 2, w1 = b < e ? (e + 3) >> 2 : w0;  // dwords that hold the document
+        uint64_t u = UNITS ? unit_base[d] : 0;  // paragraph that holds the first byte of the step
+        uint32_t nl = 0;
+        if (UNITS && lane == 0 && u < n_units) ubeg[u] = b;
+        for (uint64_t wi = w0; wi < w1; wi += 256) {
+            uint32_t ww[4];  // four independent loads in flight
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                ww[j] = i < w1 ? tw[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                const uint64_t p = i << 2;
+                const uint32_t y = ww[j] ^ 0x0A0A0A0Au;
+                uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);  // bit 7 of every byte that is '\n'
+                if (i >= w1) z = 0;
+                if (p < b || p + 4 > e) {  // first / last dword: drop bytes outside [b, e)
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (p + k < b || p + k >= e) z &= ~(0x80u << (8 * k));
+                }
+                const uint32_t c = (uint32_t)__builtin_popcount(z);
+                if (UNITS) {
+                    const uint64_t B0 = __ballot(c & 1u), B1 = __ballot(c & 2u), B2 = __ballot(c & 4u);
+                    uint64_t mine = u + __builtin_popcountll(B0 & lt) + 2 * __builtin_popcountll(B1 & lt) +
+                                    4 * __builtin_popcountll(B2 & lt);  // the paragraph this lane's first newline ends
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (z & (0x80u << (8 * k))) {
+                            if (mine + 1 < n_units) {  // unit_base is the caller's: stay inside ubeg / uend
+                                uend[mine] = p + k;
+                                ubeg[mine + 1] = p + k + 1;
+                            }
+                            mine++;
+                        }
+                    }
+                    u += __builtin_popcountll(B0) + 2 * __builtin_popcountll(B1) + 4 * __builtin_popcountll(B2);
+                } else {
+                    nl += c;
+                }
+            }
+        }
+        if (UNITS) {
+            if (lane == 0 && u < n_units) uend[u] = e;
+        } else {
+            uint32_t tot = nl;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+            if (lane == 0) units_per_doc[d] = (uint64_t)tot + 1;
+        }
+    }
+}
+
 template <bool WRITE>
 __global__ void __launch_bounds__(256) para_compact_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
                                                            const uint64_t* __restrict__ offs, uint64_t n,
@@ -117,8 +188,12 @@ extern "C" int mdd_para_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_b
     if (n_docs == 0) return MDD_OK;
     REQUIRE(offsets && units_per_doc && (text || text_bytes == 0), "mdd_para_count: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(para_scan_kernel<false>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
-                       n_docs, units_per_doc, (const uint64_t*)nullptr, (uint64_t)0, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)  // the usual case (device allocations are aligned): dword per lane
+        hipLaunchKernelGGL(para_scan4_kernel<false>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, units_per_doc, (const uint64_t*)nullptr, (uint64_t)0, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    else
+        hipLaunchKernelGGL(para_scan_kernel<false>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, units_per_doc, (const uint64_t*)nullptr, (uint64_t)0, (uint64_t*)nullptr, (uint64_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
@@ -129,8 +204,12 @@ extern "C" int mdd_para_units(mdd_ctx* ctx, const uint8_t* text, uint64_t text_b
     if (n_docs == 0) return MDD_OK;
     REQUIRE(offsets && unit_base && ubeg && uend && (text || text_bytes == 0), "mdd_para_units: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(para_scan_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
-                       n_docs, (uint64_t*)nullptr, unit_base, n_units, ubeg, uend);
+    if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)
+        hipLaunchKernelGGL(para_scan4_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, (uint64_t*)nullptr, unit_base, n_units, ubeg, uend);
+    else
+        hipLaunchKernelGGL(para_scan_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, (uint64_t*)nullptr, unit_base, n_units, ubeg, uend);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
