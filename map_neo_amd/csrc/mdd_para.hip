@@ -180,6 +180,90 @@ __global__ void __launch_bounds__(256) para_compact_kernel(const uint8_t* __rest
     }
 }
 
+// Count pass of the compaction with a dword per lane (text 4-byte aligned).  The per-byte rules of
+// para_compact_kernel add up to: kept bytes = bytes of the surviving paragraphs + one "\n" for every survivor
+// but the document's first ("\n".join), code points likewise, has_unit = a paragraph survives.  So the pass
+// only needs, per lane, the paragraph its first byte lies in (3 ballots over the lanes' newline counts) and
+// that paragraph's verdict; lanes that hold a newline walk their 4 bytes.  Sums are reduced once per document.
+__global__ void __launch_bounds__(256) para_compact_count4_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                                  const uint64_t* __restrict__ offs, uint64_t n,
+                                                                  const uint64_t* __restrict__ unit_base, uint64_t n_units,
+                                                                  const uint32_t* __restrict__ first_of, uint64_t* kept_bytes,
+                                                                  uint64_t* kept_cps, uint8_t* has_unit) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
+    auto kept_unit = [&](uint64_t u) -> bool { return u < n_units && first_of[u] == (uint32_t)u; };
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        const uint64_t w0 = b >> 2, w1 = b < e ? (e + 3) >> 2 : w0;
+        uint64_t u = unit_base[d];
+        uint32_t cnt_b = 0, cnt_c = 0, ns = (lane == 0 && kept_unit(u)) ? 1u : 0u;  // per-lane sums; ns = surviving paragraphs
+        for (uint64_t wi = w0; wi < w1; wi += 256) {
+            uint32_t ww[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                ww[j] = i < w1 ? tw[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                const uint64_t p = i << 2;
+                const uint32_t w = ww[j];
+                uint32_t in = i < w1 ? 0x80808080u : 0u;  // bytes of the dword inside [b, e), as bit 7 of each byte
+                if (p < b || p + 4 > e) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (p + k < b || p + k >= e) in &= ~(0x80u << (8 * k));
+                }
+                const uint32_t y = w ^ 0x0A0A0A0Au;
+                const uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu) & in;  // '\n' bytes
+                const uint32_t cb = w & ~(w << 1) & 0x80808080u;                                // utf-8 continuation bytes (10xxxxxx)
+                const uint32_t c = (uint32_t)__builtin_popcount(z);
+                const uint64_t B0 = __ballot(c & 1u), B1 = __ballot(c & 2u), B2 = __ballot(c & 4u);
+                uint64_t cur = u + __builtin_popcountll(B0 & lt) + 2 * __builtin_popcountll(B1 & lt) +
+                               4 * __builtin_popcountll(B2 & lt);  // paragraph of the lane's first byte
+                bool kc = in != 0u && kept_unit(cur);
+                if (c == 0u) {
+                    if (kc) {
+                        cnt_b += (uint32_t)__builtin_popcount(in);
+                        cnt_c += (uint32_t)__builtin_popcount(in & ~cb);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t f = 0x80u << (8 * k);
+                        if (z & f) {  // a newline ends `cur`; the next paragraph starts here
+                            cur++;
+                            kc = kept_unit(cur);
+                            ns += kc ? 1u : 0u;
+                        } else if ((in & f) && kc) {
+                            cnt_b++;
+                            cnt_c += (cb & f) ? 0u : 1u;
+                        }
+                    }
+                }
+                u += __builtin_popcountll(B0) + 2 * __builtin_popcountll(B1) + 4 * __builtin_popcountll(B2);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            cnt_b += (uint32_t)__shfl_xor((int)cnt_b, o, 64);
+            cnt_c += (uint32_t)__shfl_xor((int)cnt_c, o, 64);
+            ns += (uint32_t)__shfl_xor((int)ns, o, 64);
+        }
+        if (lane == 0) {
+            const uint64_t joins = ns ? ns - 1u : 0u;
+            kept_bytes[d] = (uint64_t)cnt_b + joins;
+            kept_cps[d] = (uint64_t)cnt_c + joins;
+            has_unit[d] = ns != 0u;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mdd_para_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
@@ -222,9 +306,13 @@ extern "C" int mdd_para_compact_count(mdd_ctx* ctx, const uint8_t* text, uint64_
     REQUIRE(offsets && unit_base && first_of && kept_bytes && kept_cps && has_unit && (text || text_bytes == 0),
             "mdd_para_compact_count: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(para_compact_kernel<false>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
-                       n_docs, unit_base, n_units, first_of, kept_bytes, kept_cps, has_unit, (const uint8_t*)nullptr,
-                       (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
+    if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)  // the usual case (device allocations are aligned): dword per lane
+        hipLaunchKernelGGL(para_compact_count4_kernel, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, unit_base, n_units, first_of, kept_bytes, kept_cps, has_unit);
+    else
+        hipLaunchKernelGGL(para_compact_kernel<false>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes,
+                           offsets, n_docs, unit_base, n_units, first_of, kept_bytes, kept_cps, has_unit, (const uint8_t*)nullptr,
+                           (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
