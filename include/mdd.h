@@ -236,6 +236,12 @@ int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
  * 1 <= window <= 128; text 4-byte aligned with MDD_TEXT_PAD spare bytes, text_bytes < 2^40. */
 int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                     int window, int part, int n_parts, uint64_t* table, uint64_t tab_size, uint8_t* dup);
+/*   check: mark is asynchronous and cannot validate tab_size against the (device-side) number of windows.  A window
+ *          that finds neither its content nor a free slot is counted on the device; mdd_substr_check synchronises
+ *          the stream, stores that count in *n_overflow_host (HOST, may be NULL), clears it and returns
+ *          MDD_ERR_INVALID when it is non-zero (the marks are then incomplete: redo the passes with a larger
+ *          table).  Call it after the last mark pass, before trusting dup. */
+int mdd_substr_check(mdd_ctx* ctx, uint64_t* n_overflow_host);
 int mdd_substr_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                      int window, const uint8_t* dup, uint64_t* kept_bytes, uint64_t* kept_cps);
 int mdd_substr_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,

@@ -803,12 +803,13 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     c->seg_bytes = SEG_BYTES_DEFAULT;
     c->filter_from = 0;
     c->seg_items = nullptr;
-    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 2) * sizeof(uint64_t));
+    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 4) * sizeof(uint64_t));
+    if (me == hipSuccess) me = hipMemset(c->seg_items + SEG_ITEM_CAP, 0, 4 * sizeof(uint64_t));
     if (me != hipSuccess) {
         delete c;
         return fail(MDD_ERR_HIP, "mdd_ctx_create: hipMalloc of the segment plan failed: %s", hipGetErrorString(me));
     }
-    c->seg_n_items = c->seg_items + SEG_ITEM_CAP;  // [0] = queued segments, [1] = work counter of sig_kernel
+    c->seg_n_items = c->seg_items + SEG_ITEM_CAP;  // [0] = queued segments, [1] = work counter, [2] = win_kernel probe overflows
     *out = c;
     return MDD_OK;
 }

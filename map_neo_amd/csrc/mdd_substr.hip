@@ -42,6 +42,7 @@ struct WinArgs {
     unsigned long long* table;
     uint64_t tab_size;
     uint8_t* dup;
+    unsigned long long* overflow;  // windows that found neither their content nor a free slot (table too small)
     uint32_t part, n_parts;  // this launch handles the windows whose key falls into partition `part` of `n_parts`
 };
 
@@ -129,7 +130,8 @@ __global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
                            const unsigned long long val = tag | pos;
                            uint64_t slot = __umul64hi(key, A.tab_size);
                            // the table is at most half full (caller's contract), so chains are short; the cap only keeps a
-                           // mis-sized table from spinning (windows past it are then treated as unique)
+                           // mis-sized table from spinning: a window that runs out of probes is COUNTED and
+                           // mdd_substr_check turns the count into MDD_ERR_INVALID (never a silent "unique")
                            const uint64_t max_probe = A.tab_size < 65536 ? A.tab_size : 65536;
                            for (uint64_t probe = 0; probe < max_probe; probe++) {
                                unsigned long long cur = atomicCAS(&A.table[slot], EMPTY, val);
@@ -144,6 +146,7 @@ __global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
                                }
                                slot = slot + 1 == A.tab_size ? 0 : slot + 1;
                            }
+                           atomicAdd(A.overflow, 1ull);
                        });
         item = next_item;
     }
@@ -253,6 +256,7 @@ extern "C" int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
     A.table = reinterpret_cast<unsigned long long*>(table);
     A.tab_size = tab_size;
     A.dup = dup;
+    A.overflow = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 2);
     A.part = (uint32_t)part;
     A.n_parts = (uint32_t)n_parts;
     HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
@@ -266,6 +270,22 @@ extern "C" int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(win_kernel, dim3((unsigned)waves), dim3(64), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+extern "C" int mdd_substr_check(mdd_ctx* ctx, uint64_t* n_overflow_host) {
+    REQUIRE(ctx, "mdd_substr_check: ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint64_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, ctx->seg_n_items + 2, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->seg_n_items + 2, 0, sizeof n, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_overflow_host) *n_overflow_host = n;
+    if (n)
+        return mddi::fail(MDD_ERR_INVALID,
+                          "mdd_substr_mark: %llu windows found no free table slot (tab_size too small for the windows of a "
+                          "pass: need >= 2 x windows); the marks are incomplete",
+                          (unsigned long long)n);
     return MDD_OK;
 }
 

@@ -335,6 +335,7 @@ class Engine:
                                               _ptr(table), table.numel(), _ptr(dup)), "mdd_substr_mark")
         self.last_substr_parts = n_parts
         del table
+        _lib.check(self.L.mdd_substr_check(self.ctx, None), "mdd_substr_mark")      # an undersized table is an error, not a miss
         kept_b = torch.zeros(n, dtype=torch.int64, device=self.device)
         kept_c = torch.zeros(n, dtype=torch.int64, device=self.device)
         _lib.check(self.L.mdd_substr_count(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(dup), _ptr(kept_b),

@@ -205,7 +205,7 @@ def test_stage_entry_point_parquet_device_normalisation(tmp_path, mini_docs):
     s = stage.run(stage.build_parser().parse_args(["--input_dir", str(inp), "--output_dir", str(out), "--normalize", "en",
                                                    "--workers", "2"]))
     hashed = [k for k in range(n) if docs[k] is not None]
-    lab = R.dedup([hostio.normalize_text(docs[k]) for k in hashed])["labels"]
+    lab = R.dedup([R.normalize_text(docs[k]) for k in hashed])["labels"]
     comp = {}
     for j, k in enumerate(hashed):
         comp.setdefault(int(lab[j]), []).append(k)

@@ -216,3 +216,28 @@ def test_exact_stages_match_golden_fixture(engine):
         assert [list(x) for x in exact.paragraph_dedup(engine, list(zip(ids, docs)), 0, fused=fused)] == g["paragraph_min_len_0"]
         assert [list(x) for x in exact.exact_substr_dedup(engine, list(zip(docs, ids)), 50, 20, fused=fused)] == g["substr_50_20"]
         assert [list(x) for x in exact.exact_substr_dedup(engine, list(zip(docs, ids)), 13, 0, fused=fused)] == g["substr_13_0"]
+
+
+def test_substr_undersized_table_is_an_error_not_a_miss(engine):
+    """a window table with fewer slots than distinct windows: mdd_substr_check reports MDD_ERR_INVALID and the
+    number of windows that found no slot (the kernel used to treat them as unique); a correctly sized table on
+    the same input then passes the check and equals the oracle"""
+    import ctypes as C
+    import torch
+    from map_neo_amd import lib as _lib
+    from map_neo_amd.minhash import TEXT_PAD
+    rng = np.random.Generator(np.random.PCG64(44))
+    docs = ["".join(chr(int(c)) for c in rng.integers(97, 123, 400)) for _ in range(50)]     # ~17 500 distinct windows
+    buf, offs = pack_texts(docs)
+    text, o = engine.to_device(buf), engine.to_device(offs)
+    tb = text.numel() - TEXT_PAD
+    dup = torch.zeros(tb, dtype=torch.uint8, device=engine.device)
+    small = torch.empty(1000, dtype=torch.int64, device=engine.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(engine.L.mdd_substr_mark(engine.ctx, p(text), tb, p(o), len(docs), 50, 0, 1, p(small), small.numel(), p(dup)))
+    n_over = C.c_uint64(0)
+    rc = engine.L.mdd_substr_check(engine.ctx, C.byref(n_over))
+    assert rc == -1 and n_over.value >= 17_500 - 1000 and b"tab_size too small" in engine.L.mdd_last_error()
+    assert engine.L.mdd_substr_check(engine.ctx, C.byref(n_over)) == 0 and n_over.value == 0       # the count was cleared
+    rows = [(d, i) for i, d in enumerate(docs + docs[:5])]
+    assert exact.exact_substr_dedup(engine, rows, 50, 20) == RX.exact_substr_dedup(rows, 50, 20)

@@ -64,8 +64,9 @@ def test_random_configurations(engine, seed):
 def test_random_exact_stages(engine, seed):
     """seeded random sweep over window length, minimum lengths, segment length and random utf-8 documents built
     from shared pieces (so that windows / paragraphs repeat): fused kernels == oracle restatement"""
-    from map_neo_amd import exact, hostio
+    from map_neo_amd import exact
     from oracle import ref_exact as RX
+    from oracle import ref_py as R
     rng = np.random.Generator(np.random.PCG64(2000 + seed))
     pieces = _docs(rng, 40)
     pieces = [p.replace("\n", " ") for p in pieces if p] or ["x"]
@@ -95,7 +96,7 @@ def test_random_exact_stages(engine, seed):
         t, o, f = engine.normalize_en(engine.to_device(buf), engine.to_device(offs))
         raw, oo = t.cpu().numpy().tobytes(), o.cpu().numpy()
         assert not f.any().item()
-        assert [raw[int(oo[k]):int(oo[k + 1])].decode() for k in range(len(ascii_docs))] == [hostio.normalize_text(d) for d in ascii_docs]
+        assert [raw[int(oo[k]):int(oo[k + 1])].decode() for k in range(len(ascii_docs))] == [R.normalize_text(d) for d in ascii_docs]
 
 
 @pytest.mark.parametrize("unit,width", [("char", 128), ("char", 100), ("word", 128), ("word", 32)])

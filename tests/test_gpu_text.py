@@ -1,9 +1,9 @@
 """GPU suite: EN normalisation of pure-ASCII documents on the device
-against the Python statement of EN:31-40 (hostio.normalize_text; without ftfy)."""
+against the ORACLE's statement of EN:31-40 (oracle.ref_py.normalize_text; ftfy is absent here: NFC only)."""
 import numpy as np
 import pytest
 
-from map_neo_amd import hostio
+from oracle import ref_py as R
 from map_neo_amd.minhash import as_u64, pack_texts
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +31,7 @@ def test_normalize_en_matches_python(engine):
     got, flags = _run(engine, docs)
     assert not flags.any()
     for d, g in zip(docs, got):
-        assert g == hostio.normalize_text(d.decode("ascii")).encode("ascii"), d
+        assert g == R.normalize_text(d.decode("ascii")).encode("ascii"), d
 
 
 def test_non_ascii_documents_are_flagged_not_touched(engine):
@@ -50,7 +50,7 @@ def test_long_document_and_full_pipeline_equivalence(engine):
     buf, offs = pack_texts(docs)
     t, o, f = engine.normalize_en(engine.to_device(buf), engine.to_device(offs))
     sig = engine.signatures(t, o).cpu().numpy().view(np.uint32)
-    nbuf, noffs = pack_texts([hostio.normalize_text(d) for d in docs])
+    nbuf, noffs = pack_texts([R.normalize_text(d) for d in docs])
     exp = RC.signatures(nbuf, noffs)
     assert (sig == exp).all()
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from map_neo_amd import hostio
+from oracle import ref_py as R
 
 TRICKY = [
     '{"doc_id": "a/1", "text": "plain ascii text, with Punctuation!  and   spaces\\tTabs"}',
@@ -105,7 +106,7 @@ def test_native_equals_python(tmp_path, gz, normalize_en):
         rid = nat["ids"][ridx]
         if isinstance(rid, str) and rid in rows:
             want = rows[rid]["text"]
-            want = hostio.normalize_text(want) if normalize_en else want
+            want = R.normalize_text(want) if normalize_en else want
             assert nat["text"][int(o[k]):int(o[k + 1])].tobytes().decode("utf8") == want, rid
 
 
@@ -116,7 +117,7 @@ def test_native_invalid_utf8_line_is_skipped(tmp_path):
 
 
 def test_native_ascii_normalisation_exhaustive():
-    """every ASCII byte, in context, through the native EN normaliser == hostio.normalize_text"""
+    """every ASCII byte, in context, through the native EN normaliser == the oracle's normalize_text (EN:31-40)"""
     import os
     import tempfile
     texts = ["".join(chr(c) for c in range(1, 128)), "".join(f" x{chr(c)}Y {chr(c)}" for c in range(1, 128)),
@@ -129,7 +130,7 @@ def test_native_ascii_normalisation_exhaustive():
         nat = hostio.read_jsonl_shard(p, "text", "doc_id", True, "raise", use_native=True)
     o = nat["offsets"]
     got = [nat["text"][int(o[k]):int(o[k + 1])].tobytes().decode() for k in range(len(texts))]
-    assert got == [hostio.normalize_text(t) for t in texts]
+    assert got == [R.normalize_text(t) for t in texts] == [hostio.normalize_text(t) for t in texts]
 
 
 def test_random_roundtrip_native_vs_python(tmp_path):
@@ -173,7 +174,7 @@ def test_parquet_shard_reader_matches_row_path(tmp_path):
         assert sorted(list(docs) + list(raw)) == list(range(len(exp_cand)))
         for k, i in enumerate(exp_cand):
             if k in docs:
-                assert docs[k] == (hostio.normalize_text(contents[i]) if norm else contents[i])
+                assert docs[k] == (R.normalize_text(contents[i]) if norm else contents[i])
                 assert not norm or not contents[i].isascii() or hostio._ftfy is not None
             else:
                 assert norm and raw[k] == contents[i] and contents[i].isascii()
