@@ -92,6 +92,22 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
                    uint64_t n_docs, int unit, int width, int K, const uint64_t* a, const uint64_t* b,
                    uint32_t* sig_out);
 
+/* Allocation-free variant of mdd_signatures.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory around the call -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same arguments, same results (bit for bit) as mdd_signatures; the segment queue and the two counters
+ * its kernels need live in a file-scope `static __device__` array of the library (2 MiB + 256 B per GPU, held until
+ * the process ends; its device address is resolved once per device by mdd_ctx_create with hipGetSymbolAddress)
+ * instead of the context's hipMalloc'd queue.  The call itself performs no hipMalloc / hipFree and calls no
+ * allocating routine: it only enqueues one 16-byte memset and two kernels on the context's stream.
+ * Limit: at most 2^18 queued segments, i.e. text_bytes / segment_bytes <= 262144 (4 GiB of text at the default
+ * 16 KiB segments; raise mdd_ctx_set_segment_bytes for more) -- beyond that the call fails with MDD_ERR_INVALID and
+ * enqueues nothing (mdd_signatures would lengthen the segments instead).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two contexts / streams) race; calls
+ * on one stream are ordered and each call clears the counters it needs. */
+int mdd_signatures_noalloc(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
+                           uint64_t n_docs, int unit, int width, int K, const uint64_t* a, const uint64_t* b,
+                           uint32_t* sig_out);
+
 /* Stage probe for parity tests: the shingle hashes (a2+a3: datasketch sha1_hash32 of every
  * shingle, in shingle order) of ONE document [doc_begin, doc_end) of `text`.  Writes at most
  * `cap` hashes; *n_out (device u64) receives the number of shingles of the document. */

@@ -18,6 +18,7 @@ struct mdd_ctx {
     // long-document segment plan (filled by seg_plan_kernel on every mdd_signatures call)
     uint64_t* seg_items;    // device, SEG_ITEM_CAP entries of (doc << 24 | segment)
     uint64_t* seg_n_items;  // device: [0] queued segments, [1] work counter of sig_kernel, [2] windows whose probe loop ran out (mdd_substr_check)
+    uint64_t* static_scratch;  // device address of this GPU's file-scope scratch array (mdd_signatures_noalloc)
     uint32_t seg_bytes;     // segment length in bytes (multiple of 256)
     uint32_t filter_from;   // sig_kernel filters its permute phase after this many shingles of a work item (0 = per-K default)
 };

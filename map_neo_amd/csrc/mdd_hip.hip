@@ -744,6 +744,17 @@ __global__ void __launch_bounds__(256) valu_cal_kernel(uint32_t* out, int iters,
 }
 
 
+// Allocation-free entry point (mdd_signatures_noalloc): its segment queue and counters live in this file-scope
+// device array instead of the hipMalloc'd queue of the context.  [0] = queued segments, [1] = work counter of
+// sig_kernel, [NOALLOC_HDR ..) = segment items.  Every GPU the library runs on holds its own copy at its own
+// address: the name below is only a host-side handle, the address comes from hipGetSymbolAddress (mdd_ctx_create,
+// once per device, with that device current) and is what host code passes to kernels and memsets.
+constexpr uint64_t NOALLOC_SEG_CAP = 1u << 18;  // extra segments one call can queue (2 MiB of items)
+constexpr uint64_t NOALLOC_HDR = 32;            // u64 slots before the items (keeps the items 256-byte aligned)
+static __device__ __align__(256) uint64_t scratch[NOALLOC_HDR + NOALLOC_SEG_CAP];
+constexpr int MAX_DEVICES = 64;
+uint64_t* g_scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` on each GPU (filled by mdd_ctx_create)
+
 int check_sig_common(const char* fn, mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, int unit, int width) {
     REQUIRE(ctx != nullptr, "%s: ctx is NULL", fn);
     REQUIRE(unit == MDD_UNIT_CHAR || unit == MDD_UNIT_WORD, "%s: unknown unit %d", fn, unit);
@@ -810,6 +821,21 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
         return fail(MDD_ERR_HIP, "mdd_ctx_create: hipMalloc of the segment plan failed: %s", hipGetErrorString(me));
     }
     c->seg_n_items = c->seg_items + SEG_ITEM_CAP;  // [0] = queued segments, [1] = work counter, [2] = win_kernel probe overflows
+    // device address of this GPU's copy of `scratch` (set-up work: done here, never in mdd_signatures_noalloc)
+    c->static_scratch = nullptr;
+    if (device < MAX_DEVICES) {
+        if (!g_scratch_ptr[device]) {
+            uint64_t* sp = nullptr;
+            hipError_t se = hipGetSymbolAddress(reinterpret_cast<void**>(&sp), HIP_SYMBOL(scratch));
+            if (se != hipSuccess || !sp) {
+                (void)hipFree(c->seg_items);
+                delete c;
+                return fail(MDD_ERR_HIP, "mdd_ctx_create: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(se));
+            }
+            g_scratch_ptr[device] = sp;
+        }
+        c->static_scratch = g_scratch_ptr[device];
+    }
     *out = c;
     return MDD_OK;
 }
@@ -852,14 +878,18 @@ int mdd_make_perms(uint32_t seed, int K, uint64_t* a_host, uint64_t* b_host) {
     return MDD_OK;
 }
 
-int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
-                   int unit, int width, int K, const uint64_t* a, const uint64_t* b, uint32_t* sig_out) {
-    int rc = check_sig_common("mdd_signatures", ctx, text, text_bytes, unit, width);
+// Shared body of mdd_signatures / mdd_signatures_noalloc.  `items` (item_cap entries) is the segment queue,
+// cnt[0] the queued-segment count, cnt[1] the work counter.  grow: a queue too small for text_bytes / seg_bytes
+// segments is handled by longer segments (mdd_signatures); otherwise the call is rejected (noalloc variant).
+static int signatures_impl(const char* fn, mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
+                           uint64_t n_docs, int unit, int width, int K, const uint64_t* a, const uint64_t* b, uint32_t* sig_out,
+                           uint64_t* items, uint64_t* cnt, uint64_t item_cap, bool grow) {
+    int rc = check_sig_common(fn, ctx, text, text_bytes, unit, width);
     if (rc) return rc;
-    REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "mdd_signatures: K=%d outside [1,%d]", K, MDD_MAX_PERM);
+    REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "%s: K=%d outside [1,%d]", fn, K, MDD_MAX_PERM);
     if (n_docs == 0) return MDD_OK;
-    REQUIRE(offsets && a && b && sig_out, "mdd_signatures: NULL pointer argument");
-    REQUIRE(n_docs <= 0x7FF00000ull * WAVES && n_docs < (1ull << 40), "mdd_signatures: n_docs=%llu too large for one launch",
+    REQUIRE(offsets && a && b && sig_out, "%s: NULL pointer argument", fn);
+    REQUIRE(n_docs <= 0x7FF00000ull * WAVES && n_docs < (1ull << 40), "%s: n_docs=%llu too large for one launch", fn,
             (unsigned long long)n_docs);
     HIP_TRY(hipSetDevice(ctx->device));
     SigArgs A{};
@@ -873,30 +903,54 @@ int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const
     A.a = a;
     A.b = b;
     A.sig = sig_out;
-    // segment plan: seg_bytes grows for huge inputs so that the extra segments always fit the queue
+    // segment plan: sum over docs of (ceil(len/seg) - 1) <= text_bytes / seg extra segments must fit the queue
     uint64_t seg = ctx->seg_bytes;
-    uint64_t need = text_bytes / SEG_ITEM_CAP + 1;
-    if (seg < need) seg = need;
-    seg = (seg + 255) / 256 * 256;
-    REQUIRE(seg <= 0xFFFFFF00ull, "mdd_signatures: text too large for the segment plan");
-    uint64_t max_items = text_bytes / seg;  // sum over docs of (ceil(len/seg) - 1) <= text_bytes / seg
-    if (max_items > SEG_ITEM_CAP) max_items = SEG_ITEM_CAP;
+    if (grow) {
+        uint64_t need = text_bytes / item_cap + 1;
+        if (seg < need) seg = need;
+        seg = (seg + 255) / 256 * 256;
+    } else {
+        REQUIRE(text_bytes / seg <= item_cap,
+                "%s: text_bytes=%llu with %llu-byte segments can queue more than the %llu segments of the static scratch; "
+                "raise mdd_ctx_set_segment_bytes or use mdd_signatures",
+                fn, (unsigned long long)text_bytes, (unsigned long long)seg, (unsigned long long)item_cap);
+    }
+    REQUIRE(seg <= 0xFFFFFF00ull, "%s: text too large for the segment plan", fn);
+    uint64_t max_items = text_bytes / seg;
+    if (max_items > item_cap) max_items = item_cap;
     A.seg_bytes = (uint32_t)seg;
     A.filter_from = ctx->filter_from ? (ctx->filter_from == 0xFFFFFFFFu ? 0xFFFFFFFFu : ctx->filter_from - 1u)
                                      : (uint32_t)MDD_FILTER_FROM * (uint32_t)((K + 63) / 64);
-    A.items = ctx->seg_items;
-    A.n_items = ctx->seg_n_items;
+    A.items = items;
+    A.n_items = cnt;
     A.max_items = max_items;
-    A.work_counter = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 1);
-    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));
+    A.work_counter = reinterpret_cast<unsigned long long*>(cnt + 1);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(uint64_t), ctx->stream));
     hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes,
-                       A.seg_bytes, ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, sig_out, K);
+                       A.seg_bytes, items, reinterpret_cast<unsigned long long*>(cnt), max_items, sig_out, K);
     HIP_TRY(hipGetLastError());
     // persistent grid: enough waves to fill every SIMD several times over; surplus waves find the
     // counter exhausted and leave at once
     uint64_t waves = (uint64_t)ctx->cus * 4 * 8;
     if (waves > n_docs + max_items) waves = n_docs + max_items;
     return launch_sig<false>(ctx, A, grid_for(waves, WAVES));
+}
+
+int mdd_signatures(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                   int unit, int width, int K, const uint64_t* a, const uint64_t* b, uint32_t* sig_out) {
+    REQUIRE(ctx != nullptr, "mdd_signatures: ctx is NULL");
+    return signatures_impl("mdd_signatures", ctx, text, text_bytes, offsets, n_docs, unit, width, K, a, b, sig_out,
+                           ctx->seg_items, ctx->seg_n_items, SEG_ITEM_CAP, true);
+}
+
+int mdd_signatures_noalloc(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                           int unit, int width, int K, const uint64_t* a, const uint64_t* b, uint32_t* sig_out) {
+    REQUIRE(ctx != nullptr, "mdd_signatures_noalloc: ctx is NULL");
+    uint64_t* sp = ctx->static_scratch;  // this GPU's copy of `scratch` (hipGetSymbolAddress in mdd_ctx_create)
+    REQUIRE(sp != nullptr, "mdd_signatures_noalloc: no static scratch on device %d", ctx->device);
+    // both counters are cleared by the shared body; the items of the previous call are dead once n_items is 0
+    return signatures_impl("mdd_signatures_noalloc", ctx, text, text_bytes, offsets, n_docs, unit, width, K, a, b, sig_out,
+                           sp + NOALLOC_HDR, sp, NOALLOC_SEG_CAP, false);
 }
 
 int mdd_shingle_hashes(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, uint64_t doc_begin, uint64_t doc_end,
