@@ -195,10 +195,23 @@ __device__ __noinline__ uint32_t hash_multi(const uint32_t* docw, uint32_t p, ui
 
 // wave-uniform dispatch on the longest shingle of the round
 __device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint32_t p, uint32_t L, uint32_t Lmax, bool fixed13) {
-    if (fixed13) return hash_single<4, 13>(tv, p, L);
-    if (Lmax <= 15u) return hash_single<4, 0>(tv, p, L);
-    if (Lmax <= 39u) return hash_single<10, 0>(tv, p, L);
-    if (Lmax <= 55u) return hash_single<14, 0>(tv, p, L);
+    if (fixed13) {
+        MDD_REGION("sha_a13", PR_SHA_A13);
+        return hash_single<4, 13>(tv, p, L);
+    }
+    if (Lmax <= 15u) {
+        MDD_REGION("sha4", PR_SHA4);
+        return hash_single<4, 0>(tv, p, L);
+    }
+    if (Lmax <= 39u) {
+        MDD_REGION("sha10", PR_SHA10);
+        return hash_single<10, 0>(tv, p, L);
+    }
+    if (Lmax <= 55u) {
+        MDD_REGION("sha14", PR_SHA14);
+        return hash_single<14, 0>(tv, p, L);
+    }
+    MDD_REGION("sha_multi", PR_SHA_MULTI);
     return hash_multi(tv.docw, p, L);
 }
 
@@ -284,6 +297,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     };
     uint64_t item = DUMP ? 0 : fetch();
     while (item < total) {
+        MDD_REGION("item", PR_ITEM);
         uint64_t next_item = DUMP ? total : fetch();
         uint64_t d = item;
         uint32_t seg = 0;
@@ -334,6 +348,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                     if (lane < nvalid && o < A.dump_cap) A.dump[o] = h;
                 } else {
                     // lanes >= nvalid duplicate lane 0's shingle: harmless for a min
+                    MDD_REGION("stage", PR_STAGE);
                     wave_sync();
                     lds.hbuf[lane] = h;
                     wave_sync();
@@ -368,12 +383,14 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         };
                         if (n_done < A.filter_from) {
                             for (uint32_t i = 0; i < n4; i++) {
+                                MDD_REGION("full", PR_FULL);
                                 uint4 hv = hb4[i];
                                 full(hv.x);
                                 full(hv.y);
                                 full(hv.z);
                                 full(hv.w);
                             }
+                            MDD_REGION_CONT("stage");
                         } else {
                             // Filter (pays once the minima are low, i.e. after filter_from shingles of this
                             // work item): s = lo32(t') + c with c = t' >> 61 in [0, 7], and lo32(t') needs
@@ -386,12 +403,14 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                             // (lane mask straight from v_cmp, 37 = unsigned <=); only a flagged group
                             // is tested hash by hash, against the thresholds at the group's start (a
                             // minimum lowered inside the group only makes a later test conservative).
+                            MDD_REGION("fsetup", PR_FSETUP);
                             uint32_t g[KPL];
 #pragma unroll
                             for (int q = 0; q < KPL; q++) g[q] = (m[q] < 0xFFFFFFF9u ? m[q] : 0xFFFFFFF9u) + 6u;
                             constexpr int G = KPL <= 2 ? 8 : 4;      // hashes per filter group (measured best)
                             const uint32_t ng = (n4 * 4u + G - 1) / G;  // all 64 words of hbuf are written: an over-read stays in range
                             for (uint32_t i = 0; i < ng; i++) {
+                                MDD_REGION("fgroup", PR_FGROUP);
                                 uint32_t hh[G];
 #pragma unroll
                                 for (int v = 0; v < G / 4; v++) {
@@ -415,6 +434,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                                     any |= __builtin_amdgcn_uicmp(mn, g[q], 37);
                                 }
                                 if (any == 0ull) continue;  // the usual case: no lane can use any hash of the group
+                                MDD_REGION("fdetail", PR_FDETAIL);
                                 uint64_t nb[G];
 #pragma unroll
                                 for (int e = 0; e < G; e++) {
@@ -425,13 +445,17 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                                 for (int e = 0; e < G; e++) {
                                     if (nb[e] == 0ull) continue;
+                                    MDD_REGION("ffull", PR_FFULL);
                                     full(hh[e]);
 #pragma unroll
                                     for (int q = 0; q < KPL; q++) g[q] = (m[q] < 0xFFFFFFF9u ? m[q] : 0xFFFFFFF9u) + 6u;
+                                    MDD_REGION_CONT("fdetail");
                                 }
                             }
+                            MDD_REGION_CONT("stage");
                         }
                     } else {
+                        MDD_REGION("exact", PR_EXACT);
                         for (uint32_t i = 0; i < n4; i++) {
                             uint4 hv = hb4[i];
                             uint32_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
@@ -453,6 +477,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 }
                                         });
 
+            MDD_REGION("item_end", PR_ITEM_END);
             if (DUMP) break;
             if (exact) break;
             bool risky = false;

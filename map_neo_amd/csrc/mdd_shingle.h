@@ -12,6 +12,28 @@ using namespace mddi;
 // document; a shingle is addressed by p = byte offset from docw (32 bit).  Loads run up to
 // 80 bytes past the shingle start and are NOT clamped: the caller's allocation extends
 // MDD_TEXT_PAD bytes past text_bytes (include/mdd.h).
+// Region markers for tools/isa_hist.py: an assembler COMMENT in the kernel's instruction stream (no instruction, no
+// operand) naming the source region the following code belongs to.  With -DMDD_PATHCOUNT (tools/sig_bench.hip only)
+// the same macro also counts how often the region is entered, per wave, so that static per-region instruction
+// histograms x dynamic entry counts give the executed instruction mix (profiles/r2_issue/).
+enum PathRegion { PR_ITEM, PR_ROUND, PR_SCAN, PR_SHA_A13, PR_SHA4, PR_SHA10, PR_SHA14, PR_SHA_MULTI, PR_STAGE, PR_FULL, PR_FSETUP,
+                  PR_FGROUP, PR_FDETAIL, PR_FFULL, PR_EXACT, PR_ITEM_END, PR_ASCIICHK, PR_RING, PR_COUNT };
+#ifdef MDD_PATHCOUNT
+static __device__ unsigned long long g_pathcnt[PR_COUNT];
+#define MDD_REGION(name, id)                                                                      \
+    do {                                                                                          \
+        asm volatile("; MDD_REGION " name);                                                       \
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_pathcnt[id], 1ull); \
+    } while (0)
+#define MDD_REGION_CONT(name) asm volatile("; MDD_REGION_CONT " name)  // code that continues a region already counted
+#elif defined(MDD_NO_REGION_MARKERS)  // A/B check that the comments do not change the generated code's speed
+#define MDD_REGION(name, id) ((void)0)
+#define MDD_REGION_CONT(name) ((void)0)
+#else
+#define MDD_REGION(name, id) asm volatile("; MDD_REGION " name)
+#define MDD_REGION_CONT(name) asm volatile("; MDD_REGION_CONT " name)
+#endif
+
 struct TextView {
     const uint32_t* docw;
 };
@@ -100,6 +122,7 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
         uint32_t nvalid;
         uint32_t s = 0;  // byte offset of the lane's shingle from tv.docw
         uint32_t L = 0;
+        MDD_REGION("round", PR_ROUND);
         if (ascii) {
             uint32_t rest = ascii_total - n_done;
             nvalid = rest < 64u ? rest : 64u;
@@ -112,6 +135,7 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
             for (;;) {
                 uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
                 if (scan_done || n_ent - n_done >= 64u + look) break;
+                MDD_REGION("scan", PR_SCAN);
                 // window = doc-relative bytes [pos, pos+256); lane handles 4 of them
                 uint32_t p0 = pos + 4u * lane;
                 uint32_t w4 = __builtin_amdgcn_alignbyte(pfa_hi, pfa_lo, boff);  // bytes p0 .. p0+3
@@ -185,6 +209,7 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
                     }
                 }
             }
+            MDD_REGION("ring", PR_RING);
             wave_sync();
             uint32_t n_ent = unit == MDD_UNIT_CHAR ? n_entS : n_entE;
             uint32_t rest = n_ent > n_done + look ? n_ent - look - n_done : 0u;
@@ -211,6 +236,7 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
             L = eb - sb;
         }
 
+        MDD_REGION_CONT("round");
         visit(s, L, nvalid, n_done);
         n_done += nvalid;
     }
@@ -225,7 +251,11 @@ __device__ __forceinline__ bool segment_is_ascii(const TextView& tv, uint32_t bo
     if (len) {
         uint32_t hi = (uint64_t)seg_end + width < len ? seg_end + width : len;
         uint32_t d0 = (boff + seg_beg) >> 2, d1 = (boff + hi - 1u) >> 2;
-        for (uint32_t i = d0 + lane; i <= d1; i += 64) acc |= tv.docw[i];
+        for (uint32_t i = d0 + lane; i <= d1; i += 64) {
+            MDD_REGION("asciichk", PR_ASCIICHK);
+            acc |= tv.docw[i];
+        }
+        MDD_REGION_CONT("item");
     }
     return __ballot((acc & 0x80808080u) != 0u) == 0ull;
 }

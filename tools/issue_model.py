@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""VALU issue utilisation of sig_kernel from measured parts.
+
+    python tools/issue_model.py --isa isa_regions.json --counts counts.json --ubench ubench.json \
+        [--pmc p1_counter_collection.csv] --kernel-ms 54.4 > issue_model.json
+
+  static   isa_regions.json   tools/isa_hist.py: per source region, the opcodes the compiler emitted (shipped build)
+  dynamic  counts.json        build/sig_bench_count: how often each region is entered on the workload
+  cost     ubench.json        build/ubench_valu: measured chip-wide rate of each opcode / operand form
+  check    PMC                SQ_INSTS_VALU / SALU / LDS of the same launch: static x dynamic must reproduce them
+
+executed(opcode) = sum over regions of entries(region) x static(region, opcode) / marker instances(region)
+issue_time       = sum over opcodes of executed x (64 lanes / measured lane-rate of that opcode form)
+issue_frac       = issue_time / kernel time      (<= 1: the fraction of the kernel's duration the chip's VALU issue
+                                                  ports must be busy to issue exactly these instructions)
+"""
+import argparse
+import csv
+import json
+import re
+from collections import Counter
+
+# region -> region whose entry count it shares (code that runs once per such entry without a marker of its own)
+ALIAS = {"prologue": "waves"}
+
+
+def ubench_entry(op: str, kind: str) -> str:
+    base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+    e64 = op.endswith("_e64")
+    t = {
+        "v_alignbit_b32": "alignbit_b32", "v_alignbyte_b32": "alignbyte_b32", "v_min_u32": "min_u32", "v_max_u32": "max_u32",
+        "v_min3_u32": "min3_u32", "v_max3_u32": "max3_u32", "v_lshrrev_b32": "lshrrev_b32", "v_lshlrev_b32": "lshlrev_b32",
+        "v_mad_u64_u32": "mad_u64_sdst", "v_lshl_add_u64": "lshl_add_u64", "v_readlane_b32": "readlane",
+        "v_readfirstlane_b32": "readfirstlane", "v_writelane_b32": "writelane", "v_cndmask_b32": "cndmask_e64",
+        "v_mul_lo_u32": "mul_lo_u32", "v_mul_hi_u32": "mul_hi_u32", "v_bfe_u32": "bfe_u32", "v_lshl_add_u32": "lshl_add_u32",
+        "v_and_or_b32": "and_or_b32", "v_or3_b32": "or3_b32", "v_bfi_b32": "bfi_b32", "v_not_b32": "not_b32",
+        "v_mbcnt_lo_u32_b32": "mbcnt_lo", "v_mbcnt_hi_u32_b32": "mbcnt_lo", "v_mov_b64": "mov_b64", "v_lshlrev_b64": "lshlrev_b64",
+        "v_lshrrev_b64": "lshlrev_b64", "v_xad_u32": "xad_u32", "v_sub_u32": "sub_u32", "v_subrev_u32": "sub_u32",
+        "v_add_co_u32": "add_co_u32", "v_addc_co_u32": "add_co_u32", "v_sub_co_u32": "add_co_u32", "v_subb_co_u32": "add_co_u32",
+    }
+    if base in t:
+        if base == "v_mul_lo_u32" and kind == "s":
+            return "mul_lo_sgpr"
+        return t[base]
+    if base.startswith("v_cmp"):
+        return "cmp_le_e64" if e64 else "cmp_le_e32"
+    if base == "v_bitop3_b32":
+        return "bitop3_sgpr" if kind != "v" else "bitop3_b32"
+    if base == "v_add3_u32":
+        return "add3_sgpr" if kind != "v" else "add3_u32"
+    if base == "v_perm_b32":
+        return "perm_sgpr" if kind != "v" else "perm_b32"
+    if base == "v_xor_b32":
+        return "xor_sgpr" if kind == "s" else ("xor_e64" if e64 else "xor_b32")
+    if base == "v_add_u32":
+        if e64:
+            return "add_e64_clamp"
+        return {"v": "add_u32", "l": "add_lit", "s": "add_sgpr"}[kind]
+    if base in ("v_and_b32", "v_or_b32", "v_mov_b32"):
+        if kind == "l":
+            return "and_lit"
+        if kind == "s":
+            return "add_sgpr"
+        return {"v_and_b32": "and_b32", "v_or_b32": "or_b32", "v_mov_b32": "mov_b32"}[base]
+    # anything else: price it like the generic form of its operand kind (3-operand VOP3 ops are 4-cycle class)
+    return {"v": "add3_u32", "l": "add3_sgpr", "s": "add3_sgpr"}[kind]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--isa", required=True)
+    ap.add_argument("--counts", required=True)
+    ap.add_argument("--ubench", required=True)
+    ap.add_argument("--pmc", default=None)
+    ap.add_argument("--kernel-ms", type=float, required=True)
+    ap.add_argument("--kernel-name", default="sig_kernel<2, false>")
+    ap.add_argument("--simds", type=int, default=1024)
+    ap.add_argument("--pmc2", default=None, help="csv of the pass with GRBM_GUI_ACTIVE (kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs)")
+    a = ap.parse_args()
+    isa = json.load(open(a.isa))
+    cnt = json.load(open(a.counts))
+    ub = json.load(open(a.ubench))["ops"]
+    entries = dict(cnt["regions"])
+    entries["waves"] = cnt["waves"]
+    rate = {k: v["Tops"] * 1e12 / 64.0 for k, v in ub.items()}          # wave-instructions per second, whole chip
+    cyc = {k: v.get("simd_cycles_per_op") for k, v in ub.items()}       # SIMD cycles one wave-instruction occupies the issue port
+    executed = Counter()
+    cls = Counter()
+    per_region = {}
+    for reg, body in isa["regions"].items():
+        n = entries.get(ALIAS.get(reg, reg), 0)
+        inst = max(1, body.get("instances", 1))
+        tot = Counter()
+        for key, c in body["opcodes"].items():
+            op = key.split("|")[0]
+            k = ("valu" if op.startswith("v_") else "lds" if op.startswith("ds_") else
+                 "branch" if op.startswith(("s_cbranch", "s_branch", "s_swappc", "s_setpc", "s_call")) else
+                 "misc" if op.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_setprio", "s_sleep", "s_endpgm", "s_sendmsg")) else
+                 "salu" if op.startswith("s_") and not op.startswith(("s_load", "s_buffer")) else "mem")
+            x = n * c / inst
+            tot[k] += x
+            if k == "valu":
+                executed[key] += x
+        per_region[reg] = {"entries": n, "marker_instances": inst, **{k: v for k, v in tot.items()}}
+        cls.update(tot)
+    issue_s = 0.0
+    issue_cyc = 0.0
+    by_entry = Counter()
+    unknown = Counter()
+    rows = []
+    for key, n in executed.items():
+        op, kind = key.split("|")
+        e = ubench_entry(op, kind)
+        if e not in rate:
+            unknown[e] += n
+            e = "add3_u32"
+        t = n / rate[e]
+        issue_s += t
+        issue_cyc += n * (cyc[e] or 0.0)
+        by_entry[e] += n * (cyc[e] or 0.0)
+        rows.append((n, key, e, n * (cyc[e] or 0.0)))
+    rows.sort(reverse=True)
+    out = {
+        "kernel": a.kernel_name, "workload": {k: cnt[k] for k in ("n_docs", "text_bytes", "shingles", "K", "unit", "width")},
+        "kernel_ms": a.kernel_ms,
+        "executed_wave_instructions": {k: v for k, v in cls.items()},
+        "valu_wave_instructions_per_shingle": cls["valu"] / cnt["shingles"] * 64 / 64,
+        "simds": a.simds,
+        "issue_cycles_per_simd": issue_cyc / a.simds,
+        "issue_cycles_per_shingle": issue_cyc / cnt["shingles"],
+        "avg_issue_cycles_per_valu_instruction": issue_cyc / cls["valu"],
+        "issue_frac_at_2.4GHz": issue_cyc / a.simds / (a.kernel_ms * 1e-3 * 2.4e9),
+        "time_domain": {"issue_time_ms": issue_s * 1e3, "frac": issue_s * 1e3 / a.kernel_ms,
+                        "note": "sum of executed / chip-wide rate measured per opcode in isolation; the micro-benchmarks run at "
+                                "their own (lower, power-limited) clocks, so this ratio mixes clocks -- the cycle figures do not"},
+        "issue_cycles_by_ubench_entry_share": {k: v / issue_cyc for k, v in by_entry.most_common()},
+        "top_opcodes": [{"opcode": k, "executed": n, "priced_as": e, "simd_cycles_each": cyc[e], "share": t / issue_cyc} for n, k, e, t in rows[:25]],
+        "regions": per_region,
+        "unpriced_opcodes_priced_as_add3": dict(unknown),
+    }
+    if a.pmc:
+        pm = {}
+        for r in csv.DictReader(open(a.pmc)):
+            if a.kernel_name in r["Kernel_Name"]:
+                pm.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        pm = {k: sorted(v)[len(v) // 2] for k, v in pm.items()}
+        out["pmc_per_launch"] = pm
+        out["closure"] = {c: {"model": cls[m], "pmc": pm[c], "model_over_pmc": cls[m] / pm[c]}
+                          for c, m in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_SALU", "salu"), ("SQ_INSTS_LDS", "lds")) if c in pm and pm[c]}
+    if a.pmc2:
+        pm2, dur = {}, []
+        for r in csv.DictReader(open(a.pmc2)):
+            if a.kernel_name in r["Kernel_Name"]:
+                pm2.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                if "Start_Timestamp" in r:
+                    dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
+        pm2 = {k: sorted(v)[len(v) // 2] for k, v in pm2.items()}
+        out["pmc2_per_launch"] = pm2
+        if "GRBM_GUI_ACTIVE" in pm2:
+            kc = pm2["GRBM_GUI_ACTIVE"] / 8.0
+            out["kernel_cycles_measured"] = kc
+            out["issue_frac"] = issue_cyc / a.simds / kc
+            out["issue_frac_note"] = ("VALU issue cycles the executed instruction mix needs per SIMD (per-opcode SIMD cycles measured with "
+                                      "s_memtime in build/ubench_valu) / shader cycles the launch took (GRBM_GUI_ACTIVE / 8 XCDs, same binary "
+                                      "under rocprofv3 --pmc)")
+            if dur:
+                d = sorted(dur)[len(dur) // 2]
+                out["kernel_ms_under_pmc"] = d
+                out["clock_ghz_under_pmc"] = kc / d / 1e6
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,10 @@
 // Includes the library source directly so kernel variants can be toggled with -D macros.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o build/sig_bench tools/sig_bench.hip
 //   ./build/sig_bench [n_docs] [mean_bytes] [sigma_x100] [K] [lang: 0 ascii, 1 cjk] [unit] [width] [seg_bytes] [filter_from]
+// MDD_CORPUS_FILE=path: hash that corpus instead of the built-in random text (u64 n, u64 text_bytes, u64 offsets[n+1],
+// text bytes -- written by tools/dump_corpus.py; n_docs / mean / sigma / lang arguments are then ignored).
+// Built with -DMDD_PATHCOUNT (build/sig_bench_count) the kernel also counts how often each MDD_REGION is entered
+// (one launch) and the tool prints them as JSON: the dynamic side of tools/issue_model.py.
 #include "../map_neo_amd/csrc/mdd_hip.hip"
 
 #include <cmath>
@@ -29,10 +33,25 @@ int main(int argc, char** argv) {
         if (lang == 1) len = (len / 3) * 3;
         offs[d + 1] = offs[d] + len;
     }
+    const char* cfile = getenv("MDD_CORPUS_FILE");
+    FILE* cf = nullptr;
+    if (cfile) {
+        cf = fopen(cfile, "rb");
+        uint64_t hdr[2];
+        if (!cf || fread(hdr, 8, 2, cf) != 2) { fprintf(stderr, "cannot read %s\n", cfile); return 1; }
+        n = hdr[0];
+        offs.assign(n + 1, 0);
+        if (fread(offs.data(), 8, n + 1, cf) != n + 1 || offs[n] != hdr[1]) { fprintf(stderr, "bad corpus file\n"); return 1; }
+    }
     uint64_t total = offs[n];
     std::vector<uint8_t> text(((total + 3) / 4) * 4 + MDD_TEXT_PAD, 0);
     uint64_t x = 88172645463325252ull;
-    if (lang == 0) {
+    if (cf) {
+        if (fread(text.data(), 1, total, cf) != total) { fprintf(stderr, "short corpus file\n"); return 1; }
+        fclose(cf);
+        lang = 0;
+        for (uint64_t i = 0; i < total; i++) if (text[i] & 0x80) { lang = 2; break; }
+    } else if (lang == 0) {
         for (uint64_t i = 0; i < total; i++) {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
             uint32_t r = (uint32_t)(x >> 33) % 32;
@@ -49,6 +68,7 @@ int main(int argc, char** argv) {
     for (uint64_t d = 0; d < n; d++) {
         uint64_t len = offs[d + 1] - offs[d];
         uint64_t cp = lang == 0 ? len : len / 3;
+        if (lang == 2) { cp = 0; for (uint64_t i = offs[d]; i < offs[d + 1]; i++) cp += (text[i] & 0xC0) != 0x80; }
         if (unit == 1) {  // word unit: tokens = maximal runs of non-space bytes
             cp = 0;
             for (uint64_t i = offs[d]; i < offs[d + 1]; i++)
@@ -69,6 +89,23 @@ int main(int argc, char** argv) {
     if (mdd_ctx_set_segment_bytes(ctx, seg_bytes) || mdd_ctx_set_filter_from(ctx, filter_from)) { fprintf(stderr, "%s\n", mdd_last_error()); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
+#ifdef MDD_PATHCOUNT
+    {
+        static const char* names[PR_COUNT] = {"item", "round", "scan", "sha_a13", "sha4", "sha10", "sha14", "sha_multi", "stage", "full",
+                                              "fsetup", "fgroup", "fdetail", "ffull", "exact", "item_end", "asciichk", "ring"};
+        unsigned long long zero[PR_COUNT] = {}, cnt[PR_COUNT];
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pathcnt), zero, sizeof zero));
+        if (mdd_signatures(ctx, dt, total, doff, n, unit, width, K, da, db, dsig)) { fprintf(stderr, "%s\n", mdd_last_error()); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_pathcnt), sizeof cnt));
+        uint64_t waves = (uint64_t)ctx->cus * 32;
+        printf("{\"n_docs\": %llu, \"text_bytes\": %llu, \"shingles\": %llu, \"K\": %d, \"unit\": %d, \"width\": %d, \"waves\": %llu, \"regions\": {",
+               (unsigned long long)n, (unsigned long long)total, (unsigned long long)nsh, K, unit, width, (unsigned long long)waves);
+        for (int i = 0; i < PR_COUNT; i++) printf("%s\"%s\": %llu", i ? ", " : "", names[i], cnt[i]);
+        printf("}}\n");
+        return 0;
+    }
+#endif
     for (int rep = 0; rep < 4; rep++) {
         CK(hipEventRecord(e0, 0));
         if (mdd_signatures(ctx, dt, total, doff, n, unit, width, K, da, db, dsig)) { fprintf(stderr, "%s\n", mdd_last_error()); return 1; }
