@@ -2,10 +2,13 @@
 """bench.py -- MinHash-LSH near-dedup throughput on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the whole hot path (signatures -> band records -> buckets/edges ->
-union-find -> removed mask) over a synthetic corpus already resident in HBM.
+union-find -> removed mask) over a synthetic corpus already resident in HBM (`value`); the same
+pass from packed text in PINNED HOST memory to the removed mask on the host (SURVEY.md 8(d)'s
+region) is timed next to it and reported as `pinned_host` (never `value`: task contract).
 Workload at N=1: BASELINE.json configs[1] ("C2"): 1M synthetic English docs (~2 KB avg),
-char 13-grams, num_perm=128, 9 bands x 13 rows.  For N>1 every rank holds its own C2-sized
-shard (weak scaling) and the band records are exchanged with an RCCL all-to-all.
+char 13-grams, num_perm=128, 9 bands x 13 rows.  For N>1 every rank holds one GPU's share of
+BASELINE.json configs[3] ("C4": 100M docs on 8 GPUs = 12.5M docs per GPU, weak scaling) and the
+band records are exchanged with an RCCL all-to-all.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -28,11 +31,6 @@ WIDTH, K, BANDS, ROWS = 13, 128, 9, 13
 OPS_PER_SHINGLE = lambda k: 958 + 14 * k          # SURVEY.md 8(d) algorithmic int32 ops per shingle
 PEAK_VALU_TOPS = 78.6                             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: one simple int32 op per lane per issue slot
 #                                                   (= half of the guide's 157.3 TFLOPS FP32 vector peak, which counts FMA as 2)
-# Minimum VALU issue time of the instruction stream that evaluates every (hash, permutation)
-# pair in full, in 2-cycle issue slots per shingle (DESIGN.md "Cost model"): SHA-1 single block
-# + message assembly, and per permutation 2 x v_mad_u64_u32 (2.25 each) + v_mov + v_lshrrev +
-# v_add + half a v_min3.  The shipped kernel filters most pairs out after the first shingles.
-ISSUE_SLOTS_PER_SHINGLE = lambda k: 1150 + 8.5 * k
 
 
 def _cpu_worker(args):
@@ -92,8 +90,9 @@ def cpu_baseline(n_sample: int, mean_bytes: int, seed: int):
     assert (sig_mt == sig).all()
     nbytes = int(o[-1])
     return {"value": n_sample / dt, "unit": "docs/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample}-doc corpus from the workload's generator and parameters ({nbytes / 1e6:.1f} MB), python port "
-                      f"(numpy+hashlib, per-doc MinHash like the reference) on {cores} processes, {dt:.1f} s",
+            "sample": f"BASELINE.json configs[0] (C1) in full: {n_sample} synthetic English docs ({nbytes / 1e6:.1f} MB) from the workload's "
+                      f"generator, char 13-grams, K=128, 9x13 (the reference's fixed parameters); python port (numpy+hashlib, per-doc "
+                      f"MinHash like the reference) on {cores} processes, {dt:.1f} s",
             "gb_per_s": nbytes / dt / 1e9,
             "c_port_1core_docs_per_s": n_sample / dt_c, "c_port_openmp_docs_per_s": n_sample / dt_mt,
             "c_port_openmp_threads": cores, "n_removed_sample": int((labels != np.arange(n_sample)).sum())}
@@ -143,7 +142,9 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
         from map_neo_amd import hostio
         sample = docs_of(raw, offsets, 3000)
         t0 = time.perf_counter()
-        ref = [hostio.normalize_text(d) for d in sample]
+        from oracle import ref_py as _R
+        ref = [_R.normalize_text(d) for d in sample]
+        assert ref == [hostio.normalize_text(d) for d in sample]
         dt = time.perf_counter() - t0
         assert ref == docs_of(nt, no, 3000)
         out["normalize_en"]["cpu_python_docs_per_s_1core"] = len(sample) / dt
@@ -211,9 +212,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
+    ap.add_argument("--docs", type=int, default=None,
+                    help="documents per GPU (default: 1 000 000 = C2 at N=1; 12 500 000 = one GPU's share of C4 at N>1)")
     ap.add_argument("--mean-bytes", type=int, default=2048)
-    ap.add_argument("--cpu-sample-docs", type=int, default=16000)
+    ap.add_argument("--cpu-sample-docs", type=int, default=10000,
+                    help="documents of the CPU baseline (default: BASELINE.json configs[0] in full = 10 000 docs)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the optional PCIe / pinned-host measurements")
     ap.add_argument("--stages", action="store_true", help="(default at N=1) kept for compatibility")
@@ -233,11 +236,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    seed = 20240519 + 2                           # config id 2
+    if args.docs is None:
+        args.docs = 1_000_000 if world == 1 else 12_500_000
+    config_id = 2 if args.docs * world < 50_000_000 else 4
+    seed = 20240519 + config_id                   # config id
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args.cpu_sample_docs, args.mean_bytes, seed)   # before any GPU init (uses fork)
+        cpu = cpu_baseline(args.cpu_sample_docs, args.mean_bytes, 20240519 + 1)   # C1's seed; before any GPU init (uses fork)
 
     import torch
     import torch.distributed as dist
@@ -290,6 +296,7 @@ def main():
     h2d_ms = None
     pipelined_sig_ms = None
     pipelined_equal = None
+    pinned = None
     if rank == 0 and world == 1 and text_bytes < (8 << 30) and not args.no_pcie:
         try:
             host = torch.empty(text.numel(), dtype=torch.uint8, pin_memory=True)
@@ -303,22 +310,48 @@ def main():
             torch.cuda.synchronize()
             h2d_ms = e0.elapsed_time(e1)
             del stage
-            # same signatures with the text left in pinned host memory: PCIe copies of batch b+1
-            # overlap the kernel of batch b (map_neo_amd.minhash.HostPipeline)
-            from map_neo_amd.minhash import HostPipeline
-            pipe = HostPipeline(eng)
-            offs_h = offsets.cpu().numpy()
-            pipe.signatures(host, offs_h, K, WIDTH, "char")
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            sig_p = pipe.signatures(host, offs_h, K, WIDTH, "char")
-            torch.cuda.synchronize()
-            pipelined_sig_ms = (time.perf_counter() - tp) * 1e3
-            pipelined_equal = bool(torch.equal(sig_p, eng.signatures(text, offsets, K, WIDTH, "char", text_bytes=text_bytes)))
-            del host, sig_p, pipe
+            # SURVEY 8(d)'s region: packed text + offsets in PINNED HOST memory -> removed mask on the host.  ONE
+            # signature launch hashes the documents while the text is still arriving over PCIe
+            # (mdd_signatures_from_host), then band keys / buckets / union-find, then the mask is copied back.
+            from map_neo_amd.dedup import cluster_local
+            offs_pin = offsets.cpu().pin_memory()
+            removed_pin = torch.empty(n_local, dtype=torch.uint8).pin_memory()
+            tdev = torch.empty_like(text)
+            sig_buf = torch.empty((n_local, K), dtype=torch.int32, device=dev)
+
+            def pinned_pass():
+                od = offs_pin.to(dev, non_blocking=True)
+                sg, _ = eng.signatures_from_host(host, od, K, WIDTH, "char", text_bytes=text_bytes, text_dev=tdev, out=sig_buf)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                o = cluster_local(eng, sg, BANDS, ROWS)
+                removed_pin.copy_(o["removed"], non_blocking=True)
+                return o, ev
+
+            pinned_pass()
+            eng.sync()
+            pin_ms, pin_sig_ms = [], []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True)
+                tp = time.perf_counter()
+                e0.record()
+                o, ev = pinned_pass()
+                eng.sync()                          # raises if the streamed kernel gave up waiting for its text
+                torch.cuda.synchronize()
+                pin_ms.append((time.perf_counter() - tp) * 1e3)
+                pin_sig_ms.append(e0.elapsed_time(ev))
+            pinned = {"ms_per_pass": min(pin_ms), "docs_per_s": n_local / (min(pin_ms) * 1e-3),
+                      "text_gb_per_s": text_bytes / (min(pin_ms) * 1e6), "signatures_ms": min(pin_sig_ms),
+                      "kernel_wait_wave_ms": eng.stream_wait_ms(), "n_removed": int(removed_pin.sum().item()),
+                      "region": "packed utf-8 + offsets in pinned host memory -> removed mask in pinned host memory (SURVEY 8(d)); "
+                                "best of 3 passes, wall clock around enqueue + synchronize"}
+            pipelined_sig_ms = min(pin_sig_ms)
+            pipelined_equal = bool(torch.equal(sig_buf, eng.signatures(text, offsets, K, WIDTH, "char", text_bytes=text_bytes)))
+            del host, tdev, sig_buf, o
         except Exception as e:  # pinned allocation can fail on small hosts: the figures are optional
-            print(f"[bench] PCIe figures skipped: {e}", file=sys.stderr)
-            h2d_ms = None
+            print(f"[bench] PCIe figures skipped: {e!r}", file=sys.stderr)
+            pinned = {"error": repr(e)}
     # achievable HBM bandwidth on this device (calibrate with a device copy): read + write of the text
     hbm_copy_gbps = None
     if rank == 0:
@@ -336,11 +369,13 @@ def main():
     lens = offsets[1:] - offsets[:-1]
     n_shingles = int(torch.clamp(lens - (WIDTH - 1), min=0).sum().item())      # ASCII corpus: code points == bytes
 
+    dist_timings = {}
+
     def step(timer=None):
         if not use_dist:
             return dedup_local(eng, text, offsets, K, WIDTH, "char", BANDS, ROWS, text_bytes=text_bytes, timer=timer)
         return dedup_distributed(eng, text, offsets, d0, n_global, K, WIDTH, "char", BANDS, ROWS,
-                                 text_bytes=text_bytes, timer=timer)
+                                 text_bytes=text_bytes, timer=timer, timings=dist_timings)
 
     def barrier():
         if use_dist:
@@ -369,19 +404,51 @@ def main():
         n_removed = int(nr.item())
 
     if rank == 0:
-        # HBM bytes per sig_kernel launch from the PMC passes of this same command (tools/pmc_bench.sh ->
-        # profiles/r1m_pmc_bench/summary.json, FETCH_SIZE corrected x2 as calibrated); null if the workload differs
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1m_pmc_bench", "summary.json")))
-            if pm["workload"]["text_bytes_per_gpu"] == text_bytes and pm["workload"]["docs_per_gpu"] == n_local:
-                k = pm["kernels"]["sig_kernel<2, false>"]
-                traffic = k["fetch_bytes"] + k["write_bytes"]
-        except Exception:
-            traffic = None
         ms_per_step = dt / args.steps * 1e3
         sig_ms = stages.get("signatures", 0.0) / args.steps       # HIP events on the launch stream, timed region
+        is_c2 = (n_local == 1_000_000 and args.mean_bytes == 2048)
+        # HBM bytes per sig_kernel launch: PMC passes of this same command (tools/pmc_bench.sh ->
+        # profiles/<round>_pmc_bench/summary.json, FETCH_SIZE corrected x2 as calibrated); never measured inside this
+        # run (counters need rocprofv3), so the line names the file it comes from, or null if the workload differs
+        traffic, traffic_source = None, None
+        for cand in ("r2_pmc_bench", "r1m_pmc_bench"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", cand, "summary.json")))
+                if pm["workload"]["text_bytes_per_gpu"] == text_bytes and pm["workload"]["docs_per_gpu"] == n_local:
+                    k = pm["kernels"]["sig_kernel<2, false>"]
+                    traffic, traffic_source = k["fetch_bytes"] + k["write_bytes"], "profiles/%s/summary.json" % cand
+                    break
+            except Exception:
+                pass
+        # VALU issue utilisation: the instruction mix sig_kernel executes on THIS workload (static ISA histogram x
+        # dynamic region counts, closed against SQ_INSTS_VALU) priced with per-opcode SIMD cycles measured on this
+        # chip (profiles/r2_issue/issue_model.json, tools/issue_model.py) / the cycles the launch had: kernel time
+        # measured live x 1024 SIMDs x clock.  At the 2.4 GHz peak clock this is a LOWER bound of the utilisation
+        # (the chip runs this kernel at ~2.38 GHz); it cannot exceed 1 by construction of the costs.
+        issue = None
+        try:
+            im = json.load(open(os.path.join(ROOT, "profiles", "r2_issue", "issue_model.json")))
+            w = im["workload"]
+            if (w["n_docs"], w["text_bytes"], w["shingles"], w["K"], w["width"]) == (n_local, text_bytes, n_shingles, K, WIDTH) and sig_ms:
+                cyc = im["issue_cycles_per_shingle"] * n_shingles / 1024.0
+                issue = {"issue_frac": cyc / (sig_ms * 1e-3 * 2.4e9), "clock_ghz_assumed": 2.4,
+                         "issue_frac_at_profiled_clock": cyc / (sig_ms * 1e-3 * im["clock_ghz_under_pmc"] * 1e9),
+                         "clock_ghz_profiled": im["clock_ghz_under_pmc"],
+                         "issue_cycles_per_shingle": im["issue_cycles_per_shingle"],
+                         "valu_instructions_per_shingle": im["valu_wave_instructions_per_shingle"],
+                         "avg_issue_cycles_per_valu_instruction": im["avg_issue_cycles_per_valu_instruction"],
+                         "closure_model_over_SQ_INSTS_VALU": im["closure"]["SQ_INSTS_VALU"]["model_over_pmc"],
+                         "source": "profiles/r2_issue/issue_model.json (instruction mix and per-opcode cycles: profiled; kernel time: this run)"}
+        except Exception as e:
+            print(f"[bench] issue model not applied: {e!r}", file=sys.stderr)
+        try:
+            peak_cal = eng.valu_calibrate(20000)       # measured: dependency-free v_xor / v_add mix on every CU
+        except Exception:
+            peak_cal = None
         achieved = n_shingles * OPS_PER_SHINGLE(K) / (sig_ms * 1e-3) / 1e12 if sig_ms else None
+        workload = ("C2: %d synthetic English docs per GPU (~%d B avg)" if config_id == 2 else
+                    "C4 share: %d synthetic English docs per GPU (~%d B avg; 100M docs on 8 GPUs = 12.5M per GPU), 15 %% injected near-duplicates") \
+            % (n_local, args.mean_bytes)
         res = {
             "metric": "docs/sec MinHash-LSH dedup (signatures->bands->buckets->union-find), text resident in HBM",
             "value": n_global / (dt / args.steps),
@@ -395,12 +462,15 @@ def main():
             "vs_baseline": None,
             "dtype": "u32/u64",
             "data": "synthetic",
-            "config": {"workload": "C2: %d synthetic English docs per GPU (~%d B avg), char 13-gram shingles, "
-                                   "num_perm=128, 9 bands x 13 rows, seed 1" % (n_local, args.mean_bytes),
+            "config": {"workload": workload + ", char 13-gram shingles, num_perm=128, 9 bands x 13 rows, seed 1",
                        "docs_per_gpu": n_local, "global_docs": n_global, "text_bytes_per_gpu": text_bytes,
                        "shingles_per_gpu": n_shingles, "parallelism": "dp%d" % world,
                        "path": "distributed (RCCL all-to-all + all-gather)" if use_dist else "single-GPU"},
             "text_gb_per_s": text_bytes * world / (dt / args.steps) / 1e9,
+            "resident_docs_per_s": n_global / (dt / args.steps),
+            # SURVEY 8(d)'s region (pinned host -> removed mask on host); the task contract keeps `value` HBM-resident
+            "pinned_host": pinned,
+            "pinned_host_docs_per_s": pinned.get("docs_per_s") if pinned else None,
             "n_removed": n_removed,
             # cross-check that survives any path: the generator injected this many (near-)duplicates; a path that loses
             # band records or edges removes visibly fewer documents than that
@@ -413,7 +483,12 @@ def main():
             "pcie_inclusive_docs_per_s": (n_local / ((ms_per_step + h2d_ms) * 1e-3)) if (h2d_ms and world == 1) else None,
             "roofline": {"bound": "valu", "kernel": "sig_kernel<2,false>", "achieved": achieved, "peak": PEAK_VALU_TOPS,
                          "unit": "Tops/s (int32 lane-ops)", "frac": (achieved / PEAK_VALU_TOPS) if achieved else None,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                         "frac_is": "speed-up over SURVEY 8(d)'s nominal 958 + 14 K ops per shingle executed one op per lane-slot "
+                                    "(NOT a utilisation: fused instructions and the permute-phase filter retire / skip most of them); "
+                                    "the utilisation is issue_frac",
+                         "issue_frac": issue["issue_frac"] if issue else None, "issue": issue,
+                         "peak_calibrated": peak_cal, "peak_calibrated_unit": "Tops/s measured by mdd_valu_calibrate in this run",
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_unit": "HBM bytes per launch (PMC)",
                          "algorithmic_bytes": text_bytes + 8 * (n_local + 1) + 4 * K * n_local, "kernel_ms": sig_ms,
                          "algorithmic_ops_per_shingle": OPS_PER_SHINGLE(K),
                          "hbm_view": ({"bound": "hbm", "achieved": (text_bytes + 8 * (n_local + 1) + 4 * K * n_local) / (sig_ms * 1e6),
@@ -422,16 +497,13 @@ def main():
                                        "note": "the same launch priced against HBM: <1 % of 8 TB/s, i.e. the kernel is "
                                                "nowhere near memory-bound; ~2 750 integer ops per text byte put it on the VALU"}
                                       if sig_ms else None),
-                         "unfiltered_stream_ratio": (n_shingles * ISSUE_SLOTS_PER_SHINGLE(K) / 78.6e12 / (sig_ms * 1e-3))
-                         if sig_ms else None,
-                         "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz simple int32 lane-ops; frac can exceed 1 because "
-                                 "v_mad_u64_u32 / v_add3 / v_bitop3 retire 2-5 of SURVEY 8(d)'s elementary ops per issue and "
-                                 "because the permute-phase filter proves most (hash, permutation) pairs irrelevant from the "
-                                 "low product alone; unfiltered_stream_ratio = minimum VALU issue time of the stream that "
-                                 "evaluates every pair in full (1150 + 8.5 K issue slots per shingle, DESIGN.md 4.1) / measured "
-                                 "time: 0.97 before the filter existed, > 1 now = issue work the filter removed; measured VALU "
-                                 "instruction counts: profiles/r1m_pmc_sig; traffic from profiles/r1m_pmc_bench/summary.json"},
+                         "note": "peak = 256 CU x 128 lanes/clk x 2.4 GHz simple int32 lane-ops.  issue_frac = VALU issue cycles the "
+                                 "executed instruction mix needs (per-opcode SIMD cycles measured with s_memtime; instruction counts "
+                                 "= ISA histogram x region counts, within 1 % of SQ_INSTS_VALU) / (kernel time x 1024 SIMDs x 2.4 GHz): "
+                                 "DESIGN.md 4.1, profiles/r2_issue/"},
         }
+        if use_dist:
+            res["exchange"] = {k: v for k, v in (dist_timings or {}).items()}
         # HBM-bound stages: SURVEY 8(d)'s algorithmic bytes per document against the 8 TB/s peak
         hbm_alg = {"band_keys": 4 * K + BANDS * 20, "bucket_edges": 2 * BANDS * 20, "components": BANDS * 8 + 4}
         res["hbm_stages"] = {k: {"ms": res["stage_ms_per_step_rank0"].get(k), "algorithmic_bytes_per_doc": v,

@@ -10,6 +10,11 @@
 
 #include "../../include/mdd.h"
 
+struct ReadyNote {
+    volatile uint64_t* flag;
+    uint64_t value;
+};
+
 struct mdd_ctx {
     int device;
     hipStream_t stream;
@@ -18,6 +23,17 @@ struct mdd_ctx {
     // long-document segment plan (filled by seg_plan_kernel on every mdd_signatures call)
     uint64_t* seg_items;    // device, SEG_ITEM_CAP entries of (doc << 24 | segment)
     uint64_t* seg_n_items;  // device: [0] queued segments, [1] work counter of sig_kernel, [2] windows whose probe loop ran out (mdd_substr_check)
+    // streamed input (mdd_signatures_from_host): device words the kernel polls / reports through, and the pinned host
+    // table the "bytes ready" values are copied from (one 8-byte H2D copy after each text chunk, on the copy stream)
+    uint64_t* stream_words;     // device: [0] = highest count a wave has read from the host flag, [1] = status (non-zero: a wave gave up waiting), [2] = poller lock
+    volatile uint64_t* ready_host;  // pinned host flag word: stream_base of the call + bytes of its text that have landed (only ever grows)
+    uint64_t* ready_flag_dev;   // device-side address of that word
+    uint64_t stream_base;       // flag value at which the NEXT call's text has 0 bytes
+    ReadyNote* notes;           // host: arguments of the stream-ordered host functions (2 * READY_SLOTS, alternating halves per call)
+    hipEvent_t stream_ev[2];    // end of the copy-stream work of the call that last used each half
+    hipEvent_t order_ev;        // orders the copy stream behind the compute stream at the start of a call
+    uint32_t stream_calls;      // calls so far (selects the half)
+    bool stream_pending;        // a streamed call was enqueued since the last mdd_ctx_sync
     uint64_t* static_scratch;  // device address of this GPU's file-scope scratch array (mdd_signatures_noalloc)
     uint32_t seg_bytes;     // segment length in bytes (multiple of 256)
     uint32_t filter_from;   // sig_kernel filters its permute phase after this many shingles of a work item (0 = per-K default)

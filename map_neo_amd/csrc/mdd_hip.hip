@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 
@@ -218,6 +219,15 @@ __device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint32_t p, uin
 // ------------------------------------------------------------------------------------------
 // sig_kernel
 // ------------------------------------------------------------------------------------------
+struct StreamIn {
+    const uint64_t* host_flag;  // pinned host word (device-visible address) the copy stream's host functions advance
+    uint64_t* words;            // device: [0] = highest flag value any wave has read, [1] = status, [2] = poller lock
+    uint64_t base;              // flag value at which this call's text has 0 bytes (the flag only ever grows)
+};
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 struct SigArgs {
     const uint8_t* text;
     uint64_t text_bytes;
@@ -237,6 +247,8 @@ struct SigArgs {
     const uint64_t* n_items;
     uint64_t max_items;
     unsigned long long* work_counter;  // zeroed before every launch
+    // streamed input (mdd_signatures_from_host; in.host_flag == NULL otherwise): the text arrives while the kernel runs
+    StreamIn in;
     // DUMP mode (mdd_shingle_hashes): one document, hashes written in shingle order
     uint64_t doc_begin, doc_end;
     uint32_t* dump;
@@ -244,13 +256,59 @@ struct SigArgs {
     uint64_t* dump_n;
 };
 
+// Streamed input: block until text[0, need) has landed.  The copy engine writes a chunk and then, stream-ordered, the
+// new byte count; the count is read with a system-scope acquire load (bypasses and invalidates the caches), and a
+// work item only starts once every byte it can touch -- its document plus READY_MARGIN of over-read -- is there, so no
+// cache line of the text is ever fetched before its final content exists.  EXIT CONDITION: a wave that has waited
+// STREAM_TIMEOUT_TICKS of the 100 MHz wall clock (or sees that another wave did) sets *status and leaves the kernel.
+constexpr uint64_t READY_MARGIN = 256;
+constexpr uint64_t STREAM_TIMEOUT_TICKS = 400000000ull;  // 4 s
+__device__ __forceinline__ bool wait_ready(const StreamIn& S, uint64_t need) {
+    need += S.base;
+    uint64_t t0 = 0;
+    for (uint32_t spin = 0;; spin++) {
+        // waves poll the DEVICE copy of the count; at most one wave at a time reads the host word over PCIe (thousands
+        // of waves polling host memory would eat the very link the text is arriving on) and republishes it
+        uint64_t r = uni64(__hip_atomic_load(S.words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (r < need) {
+            uint32_t got = 0;
+            if (lane_id() == 0) got = atomicCAS(reinterpret_cast<unsigned long long*>(S.words + 2), 0ull, 1ull) == 0ull ? 1u : 0u;
+            if (uni(got)) {
+                r = uni64(__hip_atomic_load(S.host_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                if (lane_id() == 0) {
+                    atomicMax(reinterpret_cast<unsigned long long*>(S.words), (unsigned long long)r);
+                    __hip_atomic_store(S.words + 2, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (r >= need) {
+            // No cache invalidation is needed (and a system-scope acquire here would flush this XCD's L2 once per
+            // document): text_dev is 256-byte aligned and the published counts are multiples of 256 (or the end of the
+            // text), so every cache line this work item can touch lies wholly below the count -- it has its final
+            // content and has never been fetched before.  The fence only pins the compiler.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (spin && lane_id() == 0)  // statistics: 100 MHz ticks waves spent waiting for input (mdd_stream_wait_ticks)
+                atomicAdd(reinterpret_cast<unsigned long long*>(S.words + 3), (unsigned long long)(uni64(wall_clock64()) - t0));
+            return true;
+        }
+        if (uni((uint32_t)__hip_atomic_load(S.words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return false;
+        uint64_t now = uni64(wall_clock64());
+        if (spin == 0) t0 = now;
+        else if (now - t0 > STREAM_TIMEOUT_TICKS) {
+            if (lane_id() == 0) atomicOr(reinterpret_cast<unsigned long long*>(S.words + 1), 1ull);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 #ifndef MDD_WPE  // waves per SIMD the register budget is set for.  The filtered permute phase is a chain of
 #define MDD_WPE 4  // dependent mad -> min -> cmp -> branch, so a 4th wave pays (+5 % ASCII, +9 % word 5-grams)
 #endif             // although 4-12 VGPRs of the non-ASCII boundary scan then live in scratch; 5 and 6 are slower
 #ifndef MDD_FILTER_FROM  // shingles of a work item hashed in full, per 64 permutations of K, before the
 #define MDD_FILTER_FROM 256  // permute phase starts filtering (measured: 512 at K = 128, 1024 at K = 256)
 #endif
-template <int KPL, bool DUMP>
+template <int KPL, bool DUMP, bool STREAM = false>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(MDD_WPE, 8))) sig_kernel(SigArgs A) {
     __shared__ WaveLds lds_all[WAVES];
     const uint32_t wave = threadIdx.x >> 6;
@@ -313,6 +371,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             end = A.doc_end;
         } else {
             doc_range(A.offsets, d, A.text_bytes, beg, end);
+        }
+        if (STREAM) {  // a separate instantiation: the resident kernel carries none of this
+            uint64_t need = end + READY_MARGIN < A.text_bytes ? end + READY_MARGIN : A.text_bytes;
+            if (!wait_ready(A.in, need)) return;  // timed out: the status word is set, the host reports it
         }
         const uint32_t len = (uint32_t)(end - beg);
         const uint32_t seg_len = DUMP ? 0xFFFFFFFFu : A.seg_bytes;
@@ -793,6 +855,17 @@ template <bool DUMP>
 int launch_sig(mdd_ctx* ctx, const SigArgs& A, unsigned grid) {
     int kpl = DUMP ? 1 : (A.K + 63) / 64;
     dim3 g(grid), b(64 * WAVES);
+    if (!DUMP && A.in.host_flag) {  // streamed input: the instantiation that waits for its text
+        switch (kpl) {
+            case 1: hipLaunchKernelGGL((sig_kernel<1, false, true>), g, b, 0, ctx->stream, A); break;
+            case 2: hipLaunchKernelGGL((sig_kernel<2, false, true>), g, b, 0, ctx->stream, A); break;
+            case 3: hipLaunchKernelGGL((sig_kernel<3, false, true>), g, b, 0, ctx->stream, A); break;
+            case 4: hipLaunchKernelGGL((sig_kernel<4, false, true>), g, b, 0, ctx->stream, A); break;
+            default: return fail(MDD_ERR_UNSUPPORTED, "K=%d needs %d perms per lane (max 4)", A.K, kpl);
+        }
+        HIP_TRY(hipGetLastError());
+        return MDD_OK;
+    }
     switch (kpl) {
         case 1: hipLaunchKernelGGL((sig_kernel<1, DUMP>), g, b, 0, ctx->stream, A); break;
         case 2: hipLaunchKernelGGL((sig_kernel<2, DUMP>), g, b, 0, ctx->stream, A); break;
@@ -839,13 +912,21 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     c->seg_bytes = SEG_BYTES_DEFAULT;
     c->filter_from = 0;
     c->seg_items = nullptr;
-    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 4) * sizeof(uint64_t));
-    if (me == hipSuccess) me = hipMemset(c->seg_items + SEG_ITEM_CAP, 0, 4 * sizeof(uint64_t));
+    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 8) * sizeof(uint64_t));
+    if (me == hipSuccess) me = hipMemset(c->seg_items + SEG_ITEM_CAP, 0, 8 * sizeof(uint64_t));
     if (me != hipSuccess) {
         delete c;
         return fail(MDD_ERR_HIP, "mdd_ctx_create: hipMalloc of the segment plan failed: %s", hipGetErrorString(me));
     }
     c->seg_n_items = c->seg_items + SEG_ITEM_CAP;  // [0] = queued segments, [1] = work counter, [2] = win_kernel probe overflows
+    c->stream_words = c->seg_items + SEG_ITEM_CAP + 4;  // 3 more words of the same allocation (zeroed above)
+    c->stream_base = 0;
+    c->ready_host = nullptr;
+    c->ready_flag_dev = nullptr;
+    c->notes = nullptr;
+    c->stream_ev[0] = c->stream_ev[1] = c->order_ev = nullptr;
+    c->stream_calls = 0;
+    c->stream_pending = false;
     // device address of this GPU's copy of `scratch` (set-up work: done here, never in mdd_signatures_noalloc)
     c->static_scratch = nullptr;
     if (device < MAX_DEVICES) {
@@ -868,6 +949,10 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
 int mdd_ctx_destroy(mdd_ctx* ctx) {
     if (!ctx) return MDD_OK;
     if (ctx->seg_items) (void)hipFree(ctx->seg_items);
+    if (ctx->ready_host) (void)hipHostFree(const_cast<uint64_t*>(ctx->ready_host));
+    delete[] ctx->notes;
+    for (hipEvent_t e : {ctx->stream_ev[0], ctx->stream_ev[1], ctx->order_ev})
+        if (e) (void)hipEventDestroy(e);
     delete ctx;
     return MDD_OK;
 }
@@ -875,6 +960,14 @@ int mdd_ctx_destroy(mdd_ctx* ctx) {
 int mdd_ctx_sync(mdd_ctx* ctx) {
     REQUIRE(ctx != nullptr, "mdd_ctx_sync: ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream_pending) {  // did a wave of a streamed launch give up waiting for its input?
+        ctx->stream_pending = false;
+        uint64_t st = 0;
+        HIP_TRY(hipMemcpy(&st, ctx->stream_words + 1, sizeof st, hipMemcpyDeviceToHost));
+        if (st)
+            return fail(MDD_ERR_HIP, "mdd_signatures_from_host: the kernel waited more than 4 s for text that never arrived "
+                                     "(copy stream stalled or failed); the signatures are incomplete");
+    }
     return MDD_OK;
 }
 
@@ -908,7 +1001,7 @@ int mdd_make_perms(uint32_t seed, int K, uint64_t* a_host, uint64_t* b_host) {
 // segments is handled by longer segments (mdd_signatures); otherwise the call is rejected (noalloc variant).
 static int signatures_impl(const char* fn, mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
                            uint64_t n_docs, int unit, int width, int K, const uint64_t* a, const uint64_t* b, uint32_t* sig_out,
-                           uint64_t* items, uint64_t* cnt, uint64_t item_cap, bool grow) {
+                           uint64_t* items, uint64_t* cnt, uint64_t item_cap, bool grow, const StreamIn* in = nullptr) {
     int rc = check_sig_common(fn, ctx, text, text_bytes, unit, width);
     if (rc) return rc;
     REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "%s: K=%d outside [1,%d]", fn, K, MDD_MAX_PERM);
@@ -950,6 +1043,7 @@ static int signatures_impl(const char* fn, mdd_ctx* ctx, const uint8_t* text, ui
     A.n_items = cnt;
     A.max_items = max_items;
     A.work_counter = reinterpret_cast<unsigned long long*>(cnt + 1);
+    if (in) A.in = *in;
     HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(uint64_t), ctx->stream));
     hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes,
                        A.seg_bytes, items, reinterpret_cast<unsigned long long*>(cnt), max_items, sig_out, K);
@@ -976,6 +1070,107 @@ int mdd_signatures_noalloc(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
     // both counters are cleared by the shared body; the items of the previous call are dead once n_items is 0
     return signatures_impl("mdd_signatures_noalloc", ctx, text, text_bytes, offsets, n_docs, unit, width, K, a, b, sig_out,
                            sp + NOALLOC_HDR, sp, NOALLOC_SEG_CAP, false);
+}
+
+int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* text_host, uint64_t text_bytes, uint8_t* text_dev,
+                             const uint64_t* offsets, uint64_t n_docs, int unit, int width, int K, const uint64_t* a,
+                             const uint64_t* b, uint32_t* sig_out, uint64_t chunk_bytes) {
+    REQUIRE(ctx != nullptr, "mdd_signatures_from_host: ctx is NULL");
+    REQUIRE(copy_stream != nullptr && (hipStream_t)copy_stream != ctx->stream,
+            "mdd_signatures_from_host: copy_stream must be a stream other than the context's");
+    REQUIRE((text_host && text_dev) || text_bytes == 0, "mdd_signatures_from_host: NULL text");
+    REQUIRE((reinterpret_cast<uintptr_t>(text_dev) & 255u) == 0, "mdd_signatures_from_host: text_dev must be 256-byte aligned");
+    if (chunk_bytes == 0) chunk_bytes = 64ull << 20;
+    REQUIRE(chunk_bytes >= (1ull << 20) && chunk_bytes % 256 == 0, "mdd_signatures_from_host: chunk_bytes must be a multiple of 256 >= 1 MiB");
+    constexpr uint64_t READY_SLOTS = 4096;
+    REQUIRE(text_bytes / chunk_bytes + 16 <= READY_SLOTS, "mdd_signatures_from_host: more than %llu chunks; raise chunk_bytes",
+            (unsigned long long)READY_SLOTS);
+    {  // argument checks of the shared body, BEFORE anything is enqueued on the copy stream
+        int vrc = check_sig_common("mdd_signatures_from_host", ctx, text_dev, text_bytes, unit, width);
+        if (vrc) return vrc;
+        REQUIRE(K >= 1 && K <= MDD_MAX_PERM, "mdd_signatures_from_host: K=%d outside [1,%d]", K, MDD_MAX_PERM);
+    }
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && a && b && sig_out, "mdd_signatures_from_host: NULL pointer argument");
+    REQUIRE(n_docs <= 0x7FF00000ull * WAVES && n_docs < (1ull << 40), "mdd_signatures_from_host: n_docs too large for one launch");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t cs = (hipStream_t)copy_stream;
+    if (!ctx->ready_host) {  // first streamed call on this context: set-up (never on a later call)
+        void* hp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocDefault));
+        ctx->ready_host = static_cast<volatile uint64_t*>(hp);
+        *ctx->ready_host = 0;
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->ready_flag_dev), hp, 0));
+        ctx->notes = new ReadyNote[2 * READY_SLOTS];
+        for (hipEvent_t* e : {&ctx->stream_ev[0], &ctx->stream_ev[1], &ctx->order_ev})
+            HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    const uint32_t half = ctx->stream_calls & 1u;
+    if (ctx->stream_calls >= 2) HIP_TRY(hipEventSynchronize(ctx->stream_ev[half]));  // the host functions that read this half have run
+    ctx->stream_calls++;
+    // The flag only ever grows: this call's text is complete at stream_base + text_bytes, so nothing is reset between
+    // calls and the call stays asynchronous.  Compute stream: clear the status word, then the kernel (which polls).  The
+    // copy stream starts behind everything the caller has enqueued on the compute stream so far (a previous kernel may
+    // still be reading text_dev).
+    StreamIn in{ctx->ready_flag_dev, ctx->stream_words, ctx->stream_base};
+    HIP_TRY(hipMemsetAsync(ctx->stream_words + 1, 0, sizeof(uint64_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->stream_words + 3, 0, sizeof(uint64_t), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->order_ev, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(cs, ctx->order_ev, 0));
+    // copy stream: a chunk, then a stream-ordered host function that publishes the byte count now valid (in pinned host
+    // memory, which the kernel can poll coherently; a count written into ordinary device memory by the copy engine is
+    // not visible to a running kernel).  The kernel is launched behind the FIRST chunk: a grid whose waves all sleep
+    // while they wait for their first bytes was measured to put the device into a slower state for the whole launch
+    // (kernel 62 instead of 54 ms, copies 44 instead of 37 ms); with one chunk of head start the copy engine (~57 GB/s)
+    // stays ahead of the hashing (~40 GB/s) and waves wait only when the kernel is faster than PCIe.
+    // If a copy cannot be enqueued the count stops short: the kernel's own time limit ends it and this call /
+    // mdd_ctx_sync report it.
+    uint64_t done = 0;
+    uint32_t k = 0;
+    hipError_t ce = hipSuccess;
+    int rc = MDD_OK;
+    bool launched = false;
+    while ((done < text_bytes || !launched) && ce == hipSuccess && rc == MDD_OK) {
+        uint64_t n = text_bytes - done < chunk_bytes ? text_bytes - done : chunk_bytes;
+        if (n) ce = hipMemcpyAsync(text_dev + done, text_host + done, n, hipMemcpyHostToDevice, cs);
+        done += n;
+        if (ce == hipSuccess) {
+            ReadyNote* nt = ctx->notes + half * READY_SLOTS + k;
+            nt->flag = ctx->ready_host;
+            nt->value = ctx->stream_base + done;
+            ce = hipLaunchHostFunc(cs, [](void* p) { ReadyNote* q = static_cast<ReadyNote*>(p); *q->flag = q->value; }, nt);
+        }
+        k++;
+        if (!launched && ce == hipSuccess) {
+            launched = true;
+            ce = hipEventRecord(ctx->order_ev, cs);
+            if (ce == hipSuccess) ce = hipStreamWaitEvent(ctx->stream, ctx->order_ev, 0);
+            if (ce == hipSuccess)
+                rc = signatures_impl("mdd_signatures_from_host", ctx, text_dev, text_bytes, offsets, n_docs, unit, width, K, a, b,
+                                     sig_out, ctx->seg_items, ctx->seg_n_items, SEG_ITEM_CAP, true, &in);
+            if (rc == MDD_OK && ce == hipSuccess) ctx->stream_pending = true;
+        }
+    }
+    ctx->stream_base += text_bytes;
+    (void)hipEventRecord(ctx->stream_ev[half], cs);
+    if (rc != MDD_OK) ce = hipErrorUnknown;  // argument error found by the shared body: nothing was launched; fix the flag below
+    if (ce != hipSuccess) {
+        // make the flag reach this call's end anyway so that LATER calls start from a consistent base; this call's
+        // kernel may then hash text that never arrived -- the error return tells the caller to discard its output
+        (void)hipLaunchHostFunc(cs, [](void* p) { ReadyNote* q = static_cast<ReadyNote*>(p); *q->flag = q->value; },
+                                &(ctx->notes[half * READY_SLOTS + READY_SLOTS - 1] = ReadyNote{ctx->ready_host, ctx->stream_base}));
+        if (rc != MDD_OK) return rc;
+        return fail(MDD_ERR_HIP, "mdd_signatures_from_host: copy failed: %s", hipGetErrorString(ce));
+    }
+    return MDD_OK;
+}
+
+int mdd_stream_wait_ticks(mdd_ctx* ctx, uint64_t* ticks_host) {
+    REQUIRE(ctx && ticks_host, "mdd_stream_wait_ticks: NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ticks_host, ctx->stream_words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MDD_OK;
 }
 
 int mdd_shingle_hashes(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, uint64_t doc_begin, uint64_t doc_end,

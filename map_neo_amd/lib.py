@@ -23,6 +23,8 @@ SIGNATURES = {
     "mdd_make_perms": (_int, [_u32, _int, _vp, _vp]),
     "mdd_signatures": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int, _int, _vp, _vp, _vp]),
     "mdd_signatures_noalloc": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int, _int, _vp, _vp, _vp]),
+    "mdd_signatures_from_host": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _int, _int, _int, _vp, _vp, _vp, _u64]),
+    "mdd_stream_wait_ticks": (_int, [_vp, _vp]),
     "mdd_shingle_hashes": (_int, [_vp, _vp, _u64, _u64, _u64, _int, _int, _vp, _u64, _vp]),
     "mdd_band_keys": (_int, [_vp, _vp, _u64, _int, _int, _int, _u64, _int, _vp, _vp]),
     "mdd_packed_keys": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),

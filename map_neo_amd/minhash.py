@@ -158,6 +158,42 @@ class Engine:
                    "mdd_signatures")
         return sig
 
+    def signatures_from_host(self, text_host: torch.Tensor, offsets: torch.Tensor, num_perm: int = NUM_PERM,
+                             width: int = WIDTH, unit: str = "char", seed: int = SEED, text_bytes: Optional[int] = None,
+                             text_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                             copy_stream: Optional["torch.cuda.Stream"] = None, chunk_bytes: int = 0):
+        """Signatures of a corpus whose text lives in PINNED host memory (uint8 tensor): one kernel launch hashes the
+        documents while the text is copied over PCIe in chunks on `copy_stream` (mdd_signatures_from_host).
+        offsets: int64 device tensor [n+1].  Returns (sig int32 [n, K], text_dev uint8 [padded])."""
+        assert text_host.dtype == torch.uint8 and not text_host.is_cuda and text_host.is_pinned()
+        assert offsets.dtype == torch.int64 and offsets.is_cuda
+        n = offsets.numel() - 1
+        if text_bytes is None:
+            text_bytes = int(offsets[-1].item()) if n > 0 else 0
+        if text_host.numel() < int(text_bytes):
+            raise _lib.MddError("text_host is shorter than text_bytes")
+        if text_dev is None:
+            text_dev = torch.empty(padded_size(text_bytes), dtype=torch.uint8, device=self.device)
+        if text_dev.numel() < int(text_bytes) + TEXT_PAD:
+            raise _lib.MddError(f"text_dev must extend {TEXT_PAD} bytes past text_bytes (minhash.padded_size)")
+        if copy_stream is None:
+            if getattr(self, "_copy_stream", None) is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            copy_stream = self._copy_stream
+        a, b = self.perms(seed, num_perm)
+        sig = out if out is not None else torch.empty((n, num_perm), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.mdd_signatures_from_host(self.ctx, C.c_void_p(copy_stream.cuda_stream), C.c_void_p(text_host.data_ptr()),
+                                                   int(text_bytes), _ptr(text_dev), _ptr(offsets), n, _lib.MDD_UNIT[unit], width,
+                                                   num_perm, _ptr(a), _ptr(b), _ptr(sig), int(chunk_bytes)),
+                   "mdd_signatures_from_host")
+        return sig, text_dev
+
+    def stream_wait_ms(self) -> float:
+        """wave-milliseconds the last signatures_from_host kernel spent waiting for text (summed over its waves)"""
+        t = C.c_uint64(0)
+        _lib.check(self.L.mdd_stream_wait_ticks(self.ctx, C.byref(t)), "mdd_stream_wait_ticks")
+        return t.value / 1e5
+
     def shingle_hashes(self, text: torch.Tensor, text_bytes: int, doc_begin: int, doc_end: int,
                        width: int = WIDTH, unit: str = "char") -> np.ndarray:
         cap = max(1, doc_end - doc_begin)

@@ -337,6 +337,36 @@ def test_host_pipeline_matches_resident(engine):
     assert torch.equal(got, ref)
 
 
+def test_signatures_from_host_streamed(engine):
+    """mdd_signatures_from_host: ONE launch hashes while the text arrives in chunks over PCIe (the kernel polls the byte
+    count the copy stream publishes).  Mixed EN/ZH documents incl. long ones (segments), 1 MiB chunks (~20 of them),
+    three calls in a row on the same context (the pinned value table alternates halves) -- always == resident."""
+    spec = corpus.CorpusSpec(30000, 700, lang="mixed", dup_frac=0.1)
+    text, offs = corpus.generate(spec, device=engine.device)
+    long_docs = ["".join(chr(0x4E00 + (i * 7 + j) % 5000) for j in range(30000)) for i in range(3)] + ["word%d " % i * 9000 for i in range(3)]
+    lbuf, loffs = pack_texts(long_docs)
+    nb = int(offs[-1].item())
+    full = torch.cat([text[:nb].cpu(), torch.from_numpy(lbuf)])
+    offs_all = torch.cat([offs.cpu(), torch.from_numpy(loffs[1:].astype(np.int64)) + nb])
+    tb = int(offs_all[-1].item())
+    host = full[: tb].clone().pin_memory()
+    dev_text = engine.to_device(np.concatenate([full[:tb].numpy(), np.zeros(((tb + 3) // 4) * 4 - tb + 128, np.uint8)]))
+    offs_d = offs_all.to(engine.device)
+    for K, width, unit in ((128, 13, "char"), (256, 13, "char"), (128, 5, "word")):
+        ref = engine.signatures(dev_text, offs_d, K, width, unit, text_bytes=tb)
+        got, tdev = engine.signatures_from_host(host, offs_d, K, width, unit, text_bytes=tb, chunk_bytes=1 << 20)  # ~25 chunks
+        engine.sync()
+        assert torch.equal(got, ref), (K, width, unit)
+        assert torch.equal(tdev[:tb], dev_text[:tb])
+    # empty corpus and a corpus smaller than the first chunk
+    e, _ = engine.signatures_from_host(torch.zeros(16, dtype=torch.uint8).pin_memory(), torch.zeros(1, dtype=torch.int64, device=engine.device))
+    assert e.shape == (0, 128)
+    buf, o = pack_texts(["the quick brown fox jumps over the lazy dog", "", "abcdefghijklm"])
+    got, _ = engine.signatures_from_host(torch.from_numpy(buf).pin_memory(), engine.to_device(o))
+    engine.sync()
+    assert torch.equal(got, engine.signatures(engine.to_device(buf), engine.to_device(o)))
+
+
 def test_forest_edges(engine):
     """forest of flattened labels reproduces the same components with at most one edge per document"""
     rng = np.random.Generator(np.random.PCG64(9))
