@@ -170,8 +170,8 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
  *   tuple(i) = tuple_base + (i / rec_per_doc)*doc_stride + (i % rec_per_doc)*band_stride
  *   SIG layout:    tuple_base = sig, rec_per_doc = bands, doc_stride = K, band_stride = rows
  *   PACKED layout: tuple_base = tuples, rec_per_doc = 1, doc_stride = rows, band_stride = 0
- * Workspace (caller-allocated): table u64[tab_size], tab_size a power of two >= 2*n_rec.
- * The call clears it.
+ * Workspace (caller-allocated): table u64[tab_size], tab_size a power of two >= 1.25*n_rec (1.5 - 2 x n_rec is the
+ * sensible range: open addressing with linear probing, one atomic per probe).  The call clears it.
  * Output: every record except the lowest-indexed one of its bucket emits one edge
  * (its document, the document of a lower-indexed record of the same bucket), appended to
  * edge_u/edge_v (u32 global doc indices; which lower record, and the order of the edges, depend

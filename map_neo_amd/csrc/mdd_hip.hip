@@ -657,22 +657,39 @@ struct TupleAddr {
 // atomic is a whole memory transaction, so one atomic per record (and no second lookup pass) is the floor here.
 constexpr unsigned long long TAB_EMPTY = ~0ULL;
 
-__device__ __forceinline__ void append_edge(uint32_t u, uint32_t v, bool have, uint32_t* edge_u, uint32_t* edge_v,
-                                            uint64_t cap, unsigned long long* n_edges) {
-    // wave-aggregated append: one atomic per wave
-    uint64_t bal = __ballot(have);
+// Edge output, staged per workgroup: a workgroup walks EDGE_TILES tiles of 256 records, collects its edges in LDS and
+// reserves their place in the output with ONE global atomic at the end.  (One atomic per wave on the single edge counter
+// was the bucket stage's real hot spot on duplicate-rich input: 141 k same-address atomics at ~11 ns each = 1.5 ms of a
+// 1.8 ms stage.)
+constexpr int EDGE_TILES = 4;
+struct EdgeStage {
+    uint32_t u[256 * EDGE_TILES], v[256 * EDGE_TILES];
+    unsigned int n;
+    unsigned long long base;
+};
+__device__ __forceinline__ void stage_edge(EdgeStage& st, uint32_t u, uint32_t v, bool have) {
+    uint64_t bal = __ballot(have);  // one LDS atomic per wave
     if (bal == 0) return;
-    uint32_t cnt = (uint32_t)__popcll(bal);
     uint32_t rank = below(bal);
-    unsigned long long base = 0;
+    unsigned int base = 0;
     int leader = __ffsll((unsigned long long)bal) - 1;
-    if ((int)lane_id() == leader) base = atomicAdd(n_edges, (unsigned long long)cnt);
-    base = ((unsigned long long)__shfl((int)(base >> 32), leader, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, leader, 64);
+    if ((int)lane_id() == leader) base = atomicAdd(&st.n, (unsigned int)__popcll(bal));
+    base = (unsigned int)__shfl((int)base, leader, 64);
     if (have) {
-        uint64_t o = base + rank;
+        st.u[base + rank] = u;
+        st.v[base + rank] = v;
+    }
+}
+// every thread of the workgroup calls this once, after its last stage_edge
+__device__ __forceinline__ void flush_edges(EdgeStage& st, uint32_t* edge_u, uint32_t* edge_v, uint64_t cap, unsigned long long* n_edges) {
+    __syncthreads();
+    if (threadIdx.x == 0 && st.n) st.base = atomicAdd(n_edges, (unsigned long long)st.n);
+    __syncthreads();
+    for (unsigned int e = threadIdx.x; e < st.n; e += blockDim.x) {
+        uint64_t o = st.base + e;
         if (o < cap) {
-            edge_u[o] = u;
-            edge_v[o] = v;
+            edge_u[o] = st.u[e];
+            edge_v[o] = st.v[e];
         }
     }
 }
@@ -685,20 +702,76 @@ __device__ __forceinline__ bool same_bucket(const TupleAddr& ta, const uint64_t*
     return same;
 }
 
+// Skew (BASELINE.json configs[4]: boilerplate-heavy corpora, the all-0xFFFFFFFF signature of short documents): a bucket
+// with a million members would put a million atomics on ONE table entry, and same-address atomics retire at ~11 ns
+// each (measured: 11.5 ms for one bucket of 1 M records against 0.5 ms for 9 M records in singleton buckets).  So the
+// 256 records of a workgroup are grouped first, in LDS: a record whose key equals that of a lower-indexed record of
+// the workgroup (and whose exact tuple equals it) links to that record directly and never touches the table; of every
+// group only the lowest record (the "leader") goes to the table, and a leader that HAS followers looks before it
+// leaps: if a plain load already shows an earlier record of its bucket in the slot, it links to that and issues no
+// atomic at all (a stale value is still an earlier record of the same bucket: the slot's bucket never changes and its
+// index only shrinks).  Hot buckets thus cost cached loads, and singleton buckets -- the normal case -- take the same
+// single atomicCAS as before.
+constexpr int BKT_LDS = 512;  // LDS grouping table entries per 256-thread workgroup
+
 __global__ void __launch_bounds__(256) bucket_insert_kernel(const uint64_t* key, const uint64_t* meta, uint64_t n_rec, TupleAddr ta,
                                                             unsigned long long* tab, uint64_t tab_mask, uint32_t* edge_u,
                                                             uint32_t* edge_v, uint64_t edge_cap, unsigned long long* n_edges,
                                                             unsigned long long* n_coll) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long g_key[BKT_LDS];
+    __shared__ unsigned int g_low[BKT_LDS];  // lowest thread of the workgroup whose key is g_key[h]
+    __shared__ unsigned int g_cnt[BKT_LDS];  // how many threads have that key
+    __shared__ EdgeStage stage;
+    if (threadIdx.x == 0) stage.n = 0;
+  for (int tile = 0; tile < EDGE_TILES; tile++) {
+    const uint64_t i = ((uint64_t)blockIdx.x * EDGE_TILES + tile) * blockDim.x + threadIdx.x;
+    const bool valid = i < n_rec;
+    __syncthreads();  // the previous tile is done with the grouping tables
+    for (int h = threadIdx.x; h < BKT_LDS; h += 256) {
+        g_low[h] = 0xFFFFFFFFu;
+        g_cnt[h] = 0;
+    }
+    unsigned long long k = valid ? key[i] : 0ULL;
+    const uint64_t mi = valid ? meta[i] : 0ULL;
+    const uint32_t h = (uint32_t)(k >> 7) & (BKT_LDS - 1);  // bits the table slot (mix64) and the tag (high half) do not use directly
+    if (valid) g_key[h] = k;  // one arbitrary writer per entry wins; the others of ITS key group around it
+    __syncthreads();
+    const bool grouped = valid && g_key[h] == k;
+    if (grouped) {
+        atomicMin(&g_low[h], threadIdx.x);
+        atomicAdd(&g_cnt[h], 1u);
+    }
+    __syncthreads();
     bool have = false;
     uint32_t eu = 0, ev = 0;
-    if (i < n_rec) {
-        unsigned long long k = key[i];
+    bool to_table = valid;
+    bool look_first = false;
+    if (grouped) {
+        const uint32_t low = g_low[h];
+        if (low != threadIdx.x) {
+            // follower: same surrogate key as a lower record of this workgroup -- same bucket iff the exact tuples agree
+            const uint64_t q = i - threadIdx.x + low;
+            if (same_bucket(ta, meta, i, mi, q)) {
+                eu = (uint32_t)mi;
+                ev = (uint32_t)meta[q];
+                have = eu != ev;
+                to_table = false;
+            }  // else: a different tuple with the same (truncated) key: goes to the table on its own
+        } else {
+            look_first = g_cnt[h] > 1u;
+        }
+    }
+    if (to_table) {
         unsigned long long val = (k & 0xFFFFFFFF00000000ULL) | (uint32_t)i;
-        uint64_t mi = meta[i];
         uint64_t slot = mix64(k) & tab_mask;
-        for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: table is never full (size >= 2*n_rec)
-            unsigned long long cur = atomicCAS(&tab[slot], TAB_EMPTY, val);
+        for (uint64_t probe = 0; probe <= tab_mask; probe++) {  // bounded: the table is never full (size >= 1.25 * n_rec)
+            unsigned long long cur;
+            if (look_first) {
+                cur = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == TAB_EMPTY || ((cur >> 32) == (val >> 32) && cur > val)) cur = atomicCAS(&tab[slot], TAB_EMPTY, val);
+            } else {
+                cur = atomicCAS(&tab[slot], TAB_EMPTY, val);
+            }
             if (cur == TAB_EMPTY) break;  // lowest record of its bucket so far
             if ((cur >> 32) == (val >> 32)) {
                 if (same_bucket(ta, meta, i, mi, (uint32_t)cur)) {
@@ -716,7 +789,9 @@ __global__ void __launch_bounds__(256) bucket_insert_kernel(const uint64_t* key,
             slot = (slot + 1) & tab_mask;
         }
     }
-    append_edge(eu, ev, have, edge_u, edge_v, edge_cap, n_edges);
+    stage_edge(stage, eu, ev, have);
+  }  // tile
+    flush_edges(stage, edge_u, edge_v, edge_cap, n_edges);
 }
 
 // Optional second pass (tests): rec_bucket[i] = lowest record index of record i's bucket
@@ -800,14 +875,20 @@ __global__ void __launch_bounds__(256) removed_kernel(const uint32_t* labels, ui
 // forest a rank ships to the others instead of its raw bucket edges
 __global__ void __launch_bounds__(256) forest_edges_kernel(const uint32_t* labels, uint64_t n, uint32_t* edge_u, uint32_t* edge_v,
                                                            uint64_t cap, unsigned long long* n_edges) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool have = false;
-    uint32_t l = 0;
-    if (i < n) {
-        l = labels[i];
-        have = l != (uint32_t)i;
+    __shared__ EdgeStage stage;
+    if (threadIdx.x == 0) stage.n = 0;
+    __syncthreads();
+    for (int tile = 0; tile < EDGE_TILES; tile++) {
+        uint64_t i = ((uint64_t)blockIdx.x * EDGE_TILES + tile) * blockDim.x + threadIdx.x;
+        bool have = false;
+        uint32_t l = 0;
+        if (i < n) {
+            l = labels[i];
+            have = l != (uint32_t)i;
+        }
+        stage_edge(stage, (uint32_t)i, l, have);
     }
-    append_edge((uint32_t)i, l, have, edge_u, edge_v, cap, n_edges);
+    flush_edges(stage, edge_u, edge_v, cap, n_edges);
 }
 
 // VALU calibration: dependency-free fast-class int32 ops (v_xor / v_add / v_lshrrev)
@@ -1264,8 +1345,8 @@ int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, ui
                      uint64_t* n_coll, uint64_t* rec_bucket) {
     REQUIRE(ctx && n_edges && n_coll, "mdd_bucket_edges: NULL counter");
     REQUIRE(n_rec <= MAX_ELEMS_PER_LAUNCH, "mdd_bucket_edges: n_rec=%llu exceeds 2^32-256", (unsigned long long)n_rec);
-    REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= 2 * n_rec,
-            "mdd_bucket_edges: tab_size=%llu must be a power of two >= 2*n_rec", (unsigned long long)tab_size);
+    REQUIRE(tab_size >= 2 && (tab_size & (tab_size - 1)) == 0 && tab_size >= n_rec + n_rec / 4,
+            "mdd_bucket_edges: tab_size=%llu must be a power of two >= 1.25*n_rec", (unsigned long long)tab_size);
     REQUIRE(rec_per_doc >= 1 && rows >= 1, "mdd_bucket_edges: bad tuple addressing");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(n_edges, 0, sizeof(uint64_t), ctx->stream));
@@ -1275,7 +1356,7 @@ int mdd_bucket_edges(mdd_ctx* ctx, const uint64_t* key, const uint64_t* meta, ui
     HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(uint64_t) * tab_size, ctx->stream));
     unsigned g = grid_for(n_rec, 256);
     TupleAddr ta{tuple_base, rec_per_doc, doc_stride, band_stride, rows};
-    hipLaunchKernelGGL(bucket_insert_kernel, dim3(g), dim3(256), 0, ctx->stream, key, meta, n_rec, ta,
+    hipLaunchKernelGGL(bucket_insert_kernel, dim3(grid_for(n_rec, 256 * EDGE_TILES)), dim3(256), 0, ctx->stream, key, meta, n_rec, ta,
                        reinterpret_cast<unsigned long long*>(table), tab_size - 1, edge_u, edge_v, edge_cap,
                        reinterpret_cast<unsigned long long*>(n_edges), reinterpret_cast<unsigned long long*>(n_coll));
     HIP_TRY(hipGetLastError());
@@ -1328,7 +1409,7 @@ int mdd_forest_edges(mdd_ctx* ctx, const uint32_t* labels, uint64_t n_docs, uint
     if (n_docs == 0) return MDD_OK;
     REQUIRE(labels && (edge_cap == 0 || (edge_u && edge_v)), "mdd_forest_edges: NULL buffer");
     REQUIRE(n_docs <= MAX_ELEMS_PER_LAUNCH, "mdd_forest_edges: n_docs exceeds one launch (2^32-256)");
-    hipLaunchKernelGGL(forest_edges_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, labels, n_docs, edge_u,
+    hipLaunchKernelGGL(forest_edges_kernel, dim3(grid_for(n_docs, 256 * EDGE_TILES)), dim3(256), 0, ctx->stream, labels, n_docs, edge_u,
                        edge_v, edge_cap, reinterpret_cast<unsigned long long*>(n_edges));
     HIP_TRY(hipGetLastError());
     return MDD_OK;

@@ -13,6 +13,7 @@ Reference functions mirrored (paths relative to /root/reference, see include/mdd
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterable, Optional, Sequence, Tuple
 
 import numpy as np
@@ -89,6 +90,8 @@ class Engine:
                        "mdd_ctx_create")
         self.ctx = h
         self._perm_cache = {}
+        # bucket table slots per band record (rounded up to a power of two): load factor <= 1 / table_factor
+        self.table_factor = float(os.environ.get("MDD_TABLE_FACTOR", "2.0"))
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -240,7 +243,7 @@ class Engine:
         met (statistics: buckets are exact), rec_bucket or None)."""
         n_rec = key.numel()
         tab_size = 2
-        while tab_size < 2 * max(1, n_rec):
+        while tab_size < self.table_factor * max(1, n_rec):
             tab_size *= 2
         table = self.empty(tab_size, torch.int64)
         eu = self.empty(max(1, n_rec), torch.int32)

@@ -474,3 +474,40 @@ def test_single_huge_document(engine):
     assert docs.tolist() == [0]
     kept = bytes(t2[: int(o2[1].item())].cpu().numpy()).decode()
     assert len(big) - len(kept) < 5000 and kept[:1000] == big[:1000] and kept[-50:] == big[-50:]
+
+
+def _skew_sig(dev, n, case, seed=7):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bucket_skew
+    return bucket_skew.make_sig(dev, n, case, seed)
+
+
+@pytest.mark.parametrize("case,n", [("one_bucket_1M", 1_100_000), ("100_buckets_10pct", 400_000), ("all_equal", 150_000)])
+def test_bucket_skew_vs_oracle(engine, case, n):
+    """BASELINE.json configs[4] (bucket skew): ONE bucket of 1 M records; 10 % of the records in 100 buckets; every document
+    in one bucket per band -- band keys + buckets + union-find against the C oracle's clustering of the same signatures,
+    and the bucket stage must not collapse on the hot entries (within 3x of the same number of singleton records + slack)"""
+    from map_neo_amd.dedup import StageTimer, cluster_local
+    sig = _skew_sig(engine.device, n, case)
+    out = cluster_local(engine, sig, want_buckets=(n <= 400_000))
+    res = RC.cluster(as_u32(sig), 9, 13, want_buckets=(n <= 400_000))
+    exp_labels = res[0]
+    assert (as_u32(out["labels"]) == exp_labels).all()
+    assert int(out["n_removed"].item()) == int((exp_labels != np.arange(n)).sum()) > 0
+    if n <= 400_000:                      # identical buckets: smallest document of every record's bucket
+        rb = as_u64(out["rec_bucket"]).reshape(n, 9)
+        exp_min = (res[2].reshape(9, n) % np.uint64(n)).T
+        assert ((rb // np.uint64(9)) == exp_min).all()
+    eu, ev = as_u32(out["edge_u"]), as_u32(out["edge_v"])
+    assert (exp_labels[eu] == exp_labels[ev]).all()
+    # timing: skewed vs the same number of records in singleton buckets
+    uni = _skew_sig(engine.device, n, "uniform")
+    ms = {}
+    for name, s in (("uniform", uni), ("skew", sig)):
+        cluster_local(engine, s)
+        tm = StageTimer()
+        tm.mark("start")
+        cluster_local(engine, s, timer=tm)
+        ms[name] = tm.result_ms()["bucket_edges"]
+    assert ms["skew"] < 3 * ms["uniform"] + 1.0, ms
