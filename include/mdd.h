@@ -164,6 +164,33 @@ int mdd_route_pack(mdd_ctx* ctx, const uint32_t* sig, int K, int bands, int rows
                    const uint64_t* meta, uint64_t n_rec, int world, uint64_t* send_cursor,
                    uint32_t* tuples_out, uint64_t* meta_out);
 
+/* Multi-GPU exchange (no counterpart in the reference, which leaves the shuffle to Spark EN:136,
+ * 140-142 / the filesystem ZH-1:58-61).  One process per GPU; the library issues the collectives itself, on the
+ * context's stream, against the RCCL the process has loaded (bound at run time with dlopen; torch's copy when torch is
+ * loaded).  mdd_comm_unique_id (rank 0; HOST buffer of MDD_COMM_ID_BYTES, to be handed to every rank by any means, e.g.
+ * torch.distributed's store) + mdd_comm_init (collective: every rank calls it) create the communicator of a context;
+ * mdd_ctx_destroy / mdd_comm_destroy release it.  world <= 64.
+ *
+ *   exchange_counts  send_counts: DEVICE u64[world] (records this rank holds for every owner: mdd_route_count).  Writes
+ *                    them to send_counts_host and what every peer holds for this rank to recv_counts_host (HOST
+ *                    u64[world] each).  SYNCHRONOUS -- the one host synchronisation of the exchange: send / recv sizes
+ *                    are host arguments and these numbers are computed on the device.
+ *   exchange_bands   band records in PACKED layout grouped by owner (mdd_route_pack) -> the records this rank owns,
+ *                    grouped by sender: tuples (rows u32 per record) and meta travel in the same send/recv group, in
+ *                    rounds of at most 512 MiB per pair and array.  recv buffers hold sum(recv_counts_host) records.
+ *   allgather_counts *n_local (DEVICE u64) of every rank -> counts_host (HOST u64[world]).  SYNCHRONOUS.
+ *   allgather_edges  edges of all ranks, rank by rank, into all_u / all_v (sum(counts_host) entries). */
+#define MDD_COMM_ID_BYTES 128
+int mdd_comm_unique_id(uint8_t* id_host);
+int mdd_comm_init(mdd_ctx* ctx, const uint8_t* id_host, int rank, int world);
+int mdd_comm_destroy(mdd_ctx* ctx);
+int mdd_exchange_counts(mdd_ctx* ctx, const uint64_t* send_counts, uint64_t* send_counts_host, uint64_t* recv_counts_host);
+int mdd_exchange_bands(mdd_ctx* ctx, const uint32_t* tuples_send, const uint64_t* meta_send, const uint64_t* send_counts_host,
+                       const uint64_t* recv_counts_host, int rows, uint32_t* tuples_recv, uint64_t* meta_recv);
+int mdd_allgather_counts(mdd_ctx* ctx, const uint64_t* n_local, uint64_t* counts_host);
+int mdd_allgather_edges(mdd_ctx* ctx, const uint32_t* edge_u, const uint32_t* edge_v, const uint64_t* counts_host,
+                        uint32_t* all_u, uint32_t* all_v);
+
 /* Bucketing + edges.  Replaces groupBy((band,key)) + generate_edges (EN:136, EN:73-80) and
  * the per-band dict of ZH-2:19-40.  Bucket identity = exact equality of (band, r-tuple).
  * Records are described by (key, meta) plus tuple addressing:

@@ -6,10 +6,20 @@ on the GPU, in any chunking.  Documents are generated already normalised (EN:31-
 identity on them): lowercase a-z pseudo-words joined by single spaces (EN), or runs of CJK
 code points (ZH, 3 utf-8 bytes each, no separators).
 
-Near-duplicates: a fraction `dup_frac` of documents copies the token stream of an earlier
-"source" document and substitutes each token with probability `edit_rate` (clusters of
-several near-copies form around popular sources).  A fraction `short_frac` of documents is
-shorter than the shingle width (they all share the all-0xFFFFFFFF signature).
+Near-duplicates: a fraction `dup_frac` of documents copies the token stream of a "source"
+document and substitutes each token with probability `edit_rate` (clusters of several
+near-copies form around popular sources).  A fraction `short_frac` of documents is shorter
+than the shingle width (they all share the all-0xFFFFFFFF signature).
+
+SURVEY 8(d) features that are OFF by default (the C2 bench corpus is the default and must not
+change): `edit_rates` (each near-copy draws its rate from the tuple, e.g. (0.01, 0.05, 0.1, 0.2)),
+`indel_rate` (token deletions + insertions: per near-copy round(indel_rate * tokens) pairs of a
+deleted and an inserted token, so lengths are preserved), `clusters="zipf50"` (C4: near-copies in
+clusters of 2-50 documents with Zipf-distributed sizes around random originals), and
+`boiler_frac` / `boiler_share` / `n_templates` (C5: boilerplate-heavy documents -- a fraction of
+the documents takes `boiler_share` of its tokens from one of `n_templates` shared templates
+chosen with Zipf popularity, which produces the skewed buckets of cookie banners, licences and
+error pages).
 """
 from __future__ import annotations
 
@@ -60,10 +70,13 @@ def _zipf_thresholds(vocab: int) -> np.ndarray:
 class CorpusSpec:
     def __init__(self, n_docs: int, mean_bytes: int = 2048, seed: int = 20240519, lang: str = "en",
                  dup_frac: float = 0.15, edit_rate: float = 0.02, short_frac: float = 0.001,
-                 sigma: float = 0.6):
-        assert lang in ("en", "zh", "mixed")
+                 sigma: float = 0.6, edit_rates: Optional[Tuple[float, ...]] = None, indel_rate: float = 0.0,
+                 clusters: str = "popular", boiler_frac: float = 0.0, boiler_share: float = 0.9, n_templates: int = 1000):
+        assert lang in ("en", "zh", "mixed") and clusters in ("popular", "zipf50")
         self.n_docs, self.mean_bytes, self.seed, self.lang = n_docs, mean_bytes, seed, lang
         self.dup_frac, self.edit_rate, self.short_frac, self.sigma = dup_frac, edit_rate, short_frac, sigma
+        self.edit_rates, self.indel_rate, self.clusters = edit_rates, indel_rate, clusters
+        self.boiler_frac, self.boiler_share, self.n_templates = boiler_frac, boiler_share, n_templates
         rng = np.random.Generator(np.random.PCG64(seed))
         n = n_docs
         # language per document
@@ -83,7 +96,16 @@ class CorpusSpec:
         is_dup = rng.random(n) < dup_frac
         is_dup[0] = False
         idx = np.nonzero(is_dup)[0]
-        if idx.size:
+        rng2 = np.random.Generator(np.random.PCG64(seed + 1000))      # draws of the optional features: a stream of their own
+        if idx.size and clusters == "zipf50":
+            # C4: clusters of 2..50 documents (1..49 near-copies of a random original), sizes ~ Zipf(s=1)
+            orig = np.nonzero(~is_dup)[0]
+            w = 1.0 / np.arange(1, 50)
+            sizes = rng2.choice(np.arange(1, 50), size=idx.size, p=w / w.sum())       # more than enough clusters
+            n_cl = int(np.searchsorted(np.cumsum(sizes), idx.size)) + 1
+            owner = np.repeat(rng2.choice(orig, n_cl, replace=n_cl > orig.size), sizes[:n_cl])[: idx.size]
+            src[rng2.permutation(idx)] = owner
+        elif idx.size:
             # pick an earlier document; squaring the uniform favours few popular sources -> clusters
             u = rng.random(idx.size) ** 2
             s = np.minimum((u * idx).astype(np.int64), idx - 1)
@@ -97,6 +119,17 @@ class CorpusSpec:
         ntok = ntok[src]                    # near-copies keep the token count of their source
         self.is_zh = self.is_zh[src]
         self.src, self.is_dup, self.ntok = src, is_dup, ntok
+        # per-document substitution rate (as a 32-bit threshold) and boilerplate template (-1: none)
+        rate = np.full(n, edit_rate)
+        if edit_rates:
+            rate = np.asarray(edit_rates, dtype=np.float64)[rng2.integers(0, len(edit_rates), n)]
+        self.rate_thr = np.minimum(rate * 2.0 ** 32, 2.0 ** 32 - 1).astype(np.int64)
+        self.template = np.full(n, -1, dtype=np.int64)
+        if boiler_frac > 0:
+            pick = rng2.random(n) < boiler_frac
+            wt = 1.0 / np.arange(1, n_templates + 1)
+            self.template[pick] = rng2.choice(n_templates, int(pick.sum()), p=wt / wt.sum())
+            self.template = self.template[src]          # a near-copy keeps its source's template
         self.thr_en = _zipf_thresholds(VOCAB_EN)
         self.thr_zh = _zipf_thresholds(VOCAB_ZH)
 
@@ -112,10 +145,33 @@ def _tokens(spec: CorpusSpec, d0: int, d1: int, device) -> Tuple[torch.Tensor, .
     src = torch.from_numpy(spec.src[d0:d1]).to(device)[doc_local]
     is_dup = torch.from_numpy(spec.is_dup[d0:d1]).to(device)[doc_local]
     is_zh = torch.from_numpy(spec.is_zh[d0:d1]).to(device)[doc_local]
-    u_src = _lsr(_h(spec.seed, src, pos), 32)
+    spos = pos
+    inserted = torch.zeros_like(is_dup)
+    if spec.indel_rate > 0:
+        # token deletions + insertions with the length preserved: pair j of a near-copy deletes the source token at
+        # q_j and inserts an own token at q2_j >= q_j; in between, the copy reads the source one position ahead
+        nt = ntok[doc_local]
+        npair = torch.clamp(torch.round(nt.to(torch.float64) * spec.indel_rate).to(torch.int64), max=8)
+        shift = torch.zeros_like(pos)
+        for j in range(8):
+            qa = _lsr(_h(spec.seed + 11 + j, doc, 0), 33) % torch.clamp(nt, min=1)
+            qb = _lsr(_h(spec.seed + 31 + j, doc, 0), 33) % torch.clamp(nt, min=1)
+            q, q2 = torch.minimum(qa, qb), torch.maximum(qa, qb)
+            on = is_dup & (npair > j)
+            shift = shift + (on & (pos >= q) & (pos < q2)).to(torch.int64)
+            inserted = inserted | (on & (pos == q2) & (q2 > q))
+        spos = torch.minimum(pos + shift, nt - 1)
+    u_src = _lsr(_h(spec.seed, src, spos), 32)
     u_own = _lsr(_h(spec.seed + 1, doc, pos), 32)
-    edit = is_dup & (_lsr(_h(spec.seed + 2, doc, pos), 32) < int(spec.edit_rate * 2 ** 32))
+    thr = torch.from_numpy(spec.rate_thr[d0:d1]).to(device)[doc_local]
+    edit = is_dup & ((_lsr(_h(spec.seed + 2, doc, pos), 32) < thr) | inserted)
     u = torch.where(edit, u_own, u_src)
+    if spec.boiler_frac > 0:
+        # boilerplate: the first boiler_share of the document's tokens come from its template's stream
+        tpl = torch.from_numpy(spec.template[d0:d1]).to(device)[doc_local]
+        nb = (ntok[doc_local].to(torch.float64) * spec.boiler_share).to(torch.int64)
+        in_tpl = (tpl >= 0) & (pos < nb) & ~edit
+        u = torch.where(in_tpl, _lsr(_h(spec.seed + 7, tpl, pos), 32), u)
     thr_en = torch.from_numpy(spec.thr_en).to(device)
     thr_zh = torch.from_numpy(spec.thr_zh).to(device)
     tok = torch.where(is_zh, torch.searchsorted(thr_zh, u).clamp_(max=VOCAB_ZH - 1),

@@ -34,6 +34,11 @@ struct mdd_ctx {
     hipEvent_t order_ev;        // orders the copy stream behind the compute stream at the start of a call
     uint32_t stream_calls;      // calls so far (selects the half)
     bool stream_pending;        // a streamed call was enqueued since the last mdd_ctx_sync
+    // multi-GPU exchange (mdd_comm.hip): RCCL communicator (ncclComm_t) + staging for the counts
+    void* comm;
+    int comm_rank, comm_world;
+    uint64_t* comm_words;       // device, 128 words
+    uint64_t* comm_words_host;  // pinned host mirror
     uint64_t* static_scratch;  // device address of this GPU's file-scope scratch array (mdd_signatures_noalloc)
     uint32_t seg_bytes;     // segment length in bytes (multiple of 256)
     uint32_t filter_from;   // sig_kernel filters its permute phase after this many shingles of a work item (0 = per-K default)

@@ -1002,6 +1002,10 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     c->seg_n_items = c->seg_items + SEG_ITEM_CAP;  // [0] = queued segments, [1] = work counter, [2] = win_kernel probe overflows
     c->stream_words = c->seg_items + SEG_ITEM_CAP + 4;  // 3 more words of the same allocation (zeroed above)
     c->stream_base = 0;
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    c->comm_words = c->comm_words_host = nullptr;
     c->ready_host = nullptr;
     c->ready_flag_dev = nullptr;
     c->notes = nullptr;
@@ -1029,6 +1033,7 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
 
 int mdd_ctx_destroy(mdd_ctx* ctx) {
     if (!ctx) return MDD_OK;
+    (void)mdd_comm_destroy(ctx);
     if (ctx->seg_items) (void)hipFree(ctx->seg_items);
     if (ctx->ready_host) (void)hipHostFree(const_cast<uint64_t*>(ctx->ready_host));
     delete[] ctx->notes;

@@ -86,7 +86,10 @@ def _host_staged(t: torch.Tensor, group=None) -> bool:
     """gloo carries CUDA tensors through the host anyway and was seen to dead-lock with several ranks on one GPU
     (rehearsals of the multi-rank path on a one-GPU box): with that backend the exchanges below are staged
     explicitly through host memory.  RCCL (backend "nccl") always works on the device buffers."""
+    import os
     import torch.distributed as dist
+    if os.environ.get("MDD_GLOO_DEVICE_TENSORS") == "1":      # diagnosis only (tools/gloo_probe.py)
+        return False
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
@@ -150,10 +153,78 @@ def _all_gather_v(t: torch.Tensor, group=None, limit_bytes: Optional[int] = None
     return torch.cat([x for p in range(world) for x in parts[p]])
 
 
+class TorchComm:
+    """The exchanges of the multi-GPU path over torch.distributed.  This is the TEST / rehearsal transport: gloo on CPU
+    tensors (tests/test_distributed_cpu.py) and gloo with every rank on one GPU (rehearsals on a one-GPU box).  The
+    product transport is NativeComm (collectives issued by libmdd_hip.so against RCCL)."""
+
+    name = "torch.distributed"
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def exchange(self, tuples_s: torch.Tensor, meta_s: torch.Tensor, send_counts: torch.Tensor, rows: int):
+        import torch.distributed as dist
+        send = [int(c) for c in send_counts.tolist()]
+        sc = torch.tensor(send, dtype=torch.int64, device=meta_s.device)
+        rc = torch.empty_like(sc)
+        if _host_staged(sc, self.group):
+            sc_h, rc_h = sc.cpu(), rc.cpu()
+            dist.all_to_all_single(rc_h, sc_h, group=self.group)
+            rc = rc_h
+        else:
+            dist.all_to_all_single(rc, sc, group=self.group)
+        recv = [int(c) for c in rc.tolist()]
+        tuples_r = _all_to_all_v(tuples_s, send, recv, rows, self.group)
+        meta_r = _all_to_all_v(meta_s, send, recv, 1, self.group)
+        return tuples_r, meta_r, send, recv
+
+    def allgather_edges(self, eu: torch.Tensor, ev: torch.Tensor):
+        return _all_gather_v(eu, self.group), _all_gather_v(ev, self.group)
+
+
+class NativeComm:
+    """The exchanges issued by libmdd_hip.so itself (include/mdd.h: mdd_comm_init, mdd_exchange_counts / _bands,
+    mdd_allgather_counts / _edges) against RCCL, on the engine's stream; torch only owns the buffers.  The
+    communicator's id travels from rank 0 to the others through the torch.distributed process group that launched
+    the job (object broadcast: plumbing).  One host synchronisation per exchange (the counts), inside the library."""
+
+    name = "libmdd_hip + RCCL"
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+        self.eng = engine
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        box = [engine.comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        engine.comm_init(box[0], self.rank, self.world)
+
+    def exchange(self, tuples_s, meta_s, send_counts, rows):
+        return self.eng.exchange_bands(tuples_s, meta_s, send_counts, rows)
+
+    def allgather_edges(self, eu, ev):
+        return self.eng.allgather_edges(eu, ev)
+
+
+def default_comm(be, group=None):
+    """NativeComm for the HIP engine under the RCCL ("nccl") backend, TorchComm otherwise (gloo: CPU tests, one-GPU
+    rehearsals; MDD_COMM=torch forces it).  Cached on the engine: a context has one communicator."""
+    import os
+    import torch.distributed as dist
+    native = (hasattr(be, "comm_init") and dist.get_backend(group) == "nccl" and os.environ.get("MDD_COMM", "native") != "torch")
+    if not native:
+        return TorchComm(group)
+    comm = getattr(be, "_native_comm", None)
+    if comm is None:
+        comm = be._native_comm = NativeComm(be, group)
+    return comm
+
+
 def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: int, n_global: int,
                       num_perm: int = NUM_PERM, width: int = WIDTH, unit: str = "char", bands: int = BANDS,
                       rows: int = ROWS, seed: int = SEED, text_bytes: Optional[int] = None, key_bits: int = 64,
-                      group=None, timings: Optional[dict] = None, timer: Optional[StageTimer] = None):
+                      group=None, timings: Optional[dict] = None, timer: Optional[StageTimer] = None, comm=None):
     """Multi-GPU path; every rank calls it with its own shard (documents doc_base ..
     doc_base+n_local of n_global).  Returns the same dict as dedup_local; labels cover all
     n_global documents (replicated), removed covers the local shard."""
@@ -162,35 +233,30 @@ def dedup_distributed(be, text: torch.Tensor, offsets: torch.Tensor, doc_base: i
     sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
     if timer is not None:
         timer.mark("signatures")
-    return cluster_distributed(be, sig, doc_base, n_global, bands, rows, key_bits, group, timings, timer)
+    return cluster_distributed(be, sig, doc_base, n_global, bands, rows, key_bits, group, timings, timer, comm)
 
 
 def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, bands: int = BANDS, rows: int = ROWS,
-                        key_bits: int = 64, group=None, timings: Optional[dict] = None, timer: Optional[StageTimer] = None):
+                        key_bits: int = 64, group=None, timings: Optional[dict] = None, timer: Optional[StageTimer] = None,
+                        comm=None):
     """Multi-GPU clustering of signatures already in HBM (row i of `sig` = global document doc_base + i):
     band records -> all-to-all by bucket owner -> local buckets -> spanning forest -> all-gather ->
-    replicated union-find.  Same return value as dedup_distributed."""
+    replicated union-find.  Same return value as dedup_distributed.  `comm` carries the two exchanges
+    (default_comm: libmdd_hip + RCCL for the HIP engine, torch.distributed for tests)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n_local = sig.shape[0]
+    if comm is None:
+        comm = default_comm(be, group)
     mark = timer.mark if timer is not None else (lambda name: None)
     key, meta = be.band_keys(sig, bands, rows, doc_base, key_bits)
     mark("band_keys")
-    # --- route band records to their owner rank (all-to-all over xGMI)
+    # --- route band records to their owner rank (all-to-all over xGMI); the counts stay on the device
     tuples_s, meta_s, send_counts = be.route(sig, key, meta, bands, rows, world)
-    send_counts = [int(c) for c in send_counts.tolist()]
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=meta_s.device)
-    rc = torch.empty_like(sc)
-    if _host_staged(sc, group):
-        sc_h, rc_h = sc.cpu(), rc.cpu()
-        dist.all_to_all_single(rc_h, sc_h, group=group)
-        rc = rc_h.to(sc.device)
-    else:
-        dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(c) for c in rc.tolist()]
-    tuples_r = _all_to_all_v(tuples_s, send_counts, recv_counts, rows, group)
-    meta_r = _all_to_all_v(meta_s, send_counts, recv_counts, 1, group)
+    mark("route")
+    tuples_r, meta_r, send_list, recv_list = comm.exchange(tuples_s, meta_s, send_counts, rows)
     mark("all_to_all")
+    del tuples_s, meta_s
     # --- local buckets over the records this rank owns
     key_r = be.packed_keys(tuples_r, meta_r, rows, key_bits)
     eu, ev, n_coll, _ = be.bucket_edges(key_r, meta_r, tuples_r, 1, rows, 0, rows, False)
@@ -205,8 +271,7 @@ def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, ban
         eu, ev = be.forest_edges(lab_local, n_local_edges)
         del lab_local
     mark("forest")
-    eu_all = _all_gather_v(eu, group)
-    ev_all = _all_gather_v(ev, group)
+    eu_all, ev_all = comm.allgather_edges(eu, ev)
     mark("all_gather")
     labels = be.components_init(n_global)
     be.components_union(labels, eu_all, ev_all)
@@ -214,10 +279,17 @@ def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, ban
     removed, n_removed = be.removed_mask(labels, doc_base, n_local)
     mark("components")
     if timings is not None:
-        timings["records_sent"] = int(sum(send_counts))
-        timings["records_received"] = int(sum(recv_counts))
+        rec_bytes = 4 * rows + 8
+        timings["transport"] = comm.name
+        timings["records_sent"] = int(sum(send_list))
+        timings["records_received"] = int(sum(recv_list))
+        timings["records_sent_to_other_ranks"] = int(sum(send_list) - send_list[dist.get_rank(group)])
+        timings["all_to_all_bytes_sent"] = int(sum(send_list)) * rec_bytes
+        timings["all_to_all_bytes_received"] = int(sum(recv_list)) * rec_bytes
+        timings["record_bytes"] = rec_bytes
         timings["edges_local"] = n_local_edges
         timings["forest_edges_local"] = int(eu.numel())
         timings["edges_global"] = int(eu_all.numel())
+        timings["all_gather_bytes_received"] = int(eu_all.numel()) * 8
     return {"sig": sig, "edge_u": eu_all, "edge_v": ev_all, "labels": labels, "removed": removed,
             "n_removed": n_removed, "n_collisions": int(n_coll)}

@@ -30,6 +30,13 @@ SIGNATURES = {
     "mdd_packed_keys": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),
     "mdd_route_count": (_int, [_vp, _vp, _u64, _int, _vp]),
     "mdd_route_pack": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _u64, _int, _vp, _vp, _vp]),
+    "mdd_comm_unique_id": (_int, [_vp]),
+    "mdd_comm_init": (_int, [_vp, _vp, _int, _int]),
+    "mdd_comm_destroy": (_int, [_vp]),
+    "mdd_exchange_counts": (_int, [_vp, _vp, _vp, _vp]),
+    "mdd_exchange_bands": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp]),
+    "mdd_allgather_counts": (_int, [_vp, _vp, _vp]),
+    "mdd_allgather_edges": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mdd_bucket_edges": (_int, [_vp, _vp, _vp, _u64, _vp, _u64, _u64, _u64, _int, _vp, _u64,
                                 _vp, _vp, _u64, _vp, _vp, _vp]),
     "mdd_components_init": (_int, [_vp, _vp, _u64]),

@@ -225,7 +225,7 @@ class Engine:
 
     def route(self, sig: torch.Tensor, key: torch.Tensor, meta: torch.Tensor, bands: int, rows: int, world: int):
         """Group band records by destination rank ((key>>32) % world) in PACKED layout.
-        Returns (tuples int32[n_rec*rows], meta int64[n_rec], counts int64[world] on host)."""
+        Returns (tuples int32[n_rec*rows], meta int64[n_rec], counts int64[world] on the DEVICE)."""
         n, K = sig.shape
         n_rec = key.numel()
         counts = torch.zeros(world, dtype=torch.int64, device=self.device)
@@ -235,7 +235,45 @@ class Engine:
         meta_out = self.empty(n_rec, torch.int64)
         _lib.check(self.L.mdd_route_pack(self.ctx, _ptr(sig), K, bands, rows, _ptr(key), _ptr(meta), n_rec, world,
                                          _ptr(cursor), _ptr(tuples), _ptr(meta_out)), "mdd_route_pack")
-        return tuples, meta_out, counts.cpu()
+        return tuples, meta_out, counts
+
+    # ------------------------------------------------------------------ multi-GPU exchange (mdd_comm.hip)
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _lib.check(self.L.mdd_comm_unique_id(buf), "mdd_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """collective: every rank of the job calls it with rank 0's unique id"""
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self.L.mdd_comm_init(self.ctx, buf, int(rank), int(world)), "mdd_comm_init")
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def exchange_bands(self, tuples_s: torch.Tensor, meta_s: torch.Tensor, send_counts: torch.Tensor, rows: int):
+        """band records grouped by owner (route) -> the records this rank owns; send_counts: int64 DEVICE tensor [world].
+        Returns (tuples int32 [n*rows], meta int64 [n], send counts, recv counts (python lists))."""
+        W = self.comm_world
+        sc_h = (C.c_uint64 * W)()
+        rc_h = (C.c_uint64 * W)()
+        _lib.check(self.L.mdd_exchange_counts(self.ctx, _ptr(send_counts), sc_h, rc_h), "mdd_exchange_counts")
+        n_recv = sum(rc_h)
+        tuples_r = self.empty(n_recv * rows, torch.int32)
+        meta_r = self.empty(n_recv, torch.int64)
+        _lib.check(self.L.mdd_exchange_bands(self.ctx, _ptr(tuples_s), _ptr(meta_s), sc_h, rc_h, rows, _ptr(tuples_r), _ptr(meta_r)),
+                   "mdd_exchange_bands")
+        return tuples_r, meta_r, list(sc_h), list(rc_h)
+
+    def allgather_edges(self, eu: torch.Tensor, ev: torch.Tensor):
+        """edges of every rank, rank by rank (int32 device tensors)"""
+        W = self.comm_world
+        n_local = torch.tensor([eu.numel()], dtype=torch.int64, device=self.device)
+        cnt = (C.c_uint64 * W)()
+        _lib.check(self.L.mdd_allgather_counts(self.ctx, _ptr(n_local), cnt), "mdd_allgather_counts")
+        total = sum(cnt)
+        all_u, all_v = self.empty(total, torch.int32), self.empty(total, torch.int32)
+        _lib.check(self.L.mdd_allgather_edges(self.ctx, _ptr(eu), _ptr(ev), cnt, _ptr(all_u), _ptr(all_v)), "mdd_allgather_edges")
+        return all_u, all_v
 
     def bucket_edges(self, key: torch.Tensor, meta: torch.Tensor, tuple_base: torch.Tensor, rec_per_doc: int,
                      doc_stride: int, band_stride: int, rows: int, want_buckets: bool = False):

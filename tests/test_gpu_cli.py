@@ -397,6 +397,56 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+def test_native_rccl_comm_one_rank(tmp_path):
+    """the product transport of the multi-GPU path -- collectives issued by libmdd_hip.so against RCCL (mdd_comm_init,
+    mdd_exchange_counts / _bands, mdd_allgather_counts / _edges) -- with the one rank a one-GPU box allows: same labels
+    and removed set as the single-GPU path, the exchange statistics add up, and a second communicator is refused"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "native.py"
+    script.write_text(f'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from map_neo_amd import corpus, lib
+from map_neo_amd.dedup import NativeComm, dedup_distributed, dedup_local, default_comm
+from map_neo_amd.minhash import Engine
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+eng = Engine(0)
+spec = corpus.CorpusSpec(40000, 600, lang="mixed", seed=31, dup_frac=0.2, edit_rate=0.005)
+text, offs = corpus.generate(spec, device=eng.device)
+ref = dedup_local(eng, text, offs)
+for K, bands, rows in ((128, 9, 13), (256, 20, 12)):
+    ref = dedup_local(eng, text, offs, K, 13, "char", bands, rows)
+    tm = {{}}
+    out = dedup_distributed(eng, text, offs, 0, spec.n_docs, K, 13, "char", bands, rows, timings=tm)
+    assert isinstance(default_comm(eng), NativeComm) and tm["transport"] == "libmdd_hip + RCCL", tm
+    assert torch.equal(out["labels"], ref["labels"]) and torch.equal(out["removed"], ref["removed"])
+    assert tm["records_sent"] == tm["records_received"] == spec.n_docs * bands and tm["records_sent_to_other_ranks"] == 0
+    assert tm["all_to_all_bytes_sent"] == spec.n_docs * bands * (4 * rows + 8)
+    assert tm["edges_global"] == tm["forest_edges_local"] <= tm["edges_local"]
+try:
+    eng.comm_init(eng.comm_unique_id(), 0, 1)
+    raise SystemExit("a second communicator was accepted")
+except lib.MddError as e:
+    assert "already has a communicator" in str(e)
+# an engine without a communicator refuses the exchange calls
+e2 = Engine(0)
+try:
+    e2.comm_world = 1
+    e2.allgather_edges(out["edge_u"], out["edge_v"])
+    raise SystemExit("exchange without mdd_comm_init was accepted")
+except lib.MddError as e:
+    assert "mdd_comm_init first" in str(e)
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 100), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=150, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 DIST_REHEARSAL = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist

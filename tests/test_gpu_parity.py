@@ -511,3 +511,22 @@ def test_bucket_skew_vs_oracle(engine, case, n):
         cluster_local(engine, s, timer=tm)
         ms[name] = tm.result_ms()["bucket_edges"]
     assert ms["skew"] < 3 * ms["uniform"] + 1.0, ms
+
+
+def test_c5_boilerplate_heavy_corpus_vs_oracle(engine):
+    """BASELINE.json configs[4] in small: long documents, 8 % boilerplate-heavy ones (Zipf-popular templates -> skewed buckets),
+    near-copies with an edit-rate sweep and token insertions / deletions, clusters of 2-50; all three (b, r, K) settings"""
+    spec = corpus.CorpusSpec(6000, 5000, seed=20240519 + 5, lang="mixed", dup_frac=0.2, edit_rates=(0.01, 0.05, 0.1, 0.2),
+                             indel_rate=0.003, clusters="zipf50", boiler_frac=0.08, boiler_share=0.92, n_templates=12)
+    text, offs = corpus.generate_chunked(spec, engine.device, docs_per_chunk=2048)
+    th, oh = text.cpu().numpy(), offs.cpu().numpy().astype(np.uint64)
+    biggest = 0
+    for (b, r, K) in [(9, 13, 128), (14, 9, 128), (20, 12, 256)]:
+        out = dedup_local(engine, text, offs, K, 13, "char", b, r)
+        exp_sig = RC.signatures(th, oh, K, 13, "char", threads=8)
+        assert (as_u32(out["sig"]) == exp_sig).all()
+        exp_labels, _ = RC.cluster(exp_sig, b, r)
+        assert (as_u32(out["labels"]) == exp_labels).all()
+        assert int(out["n_removed"].item()) == int((exp_labels != np.arange(spec.n_docs)).sum())
+        biggest = max(biggest, int(np.bincount(exp_labels).max()))
+    assert biggest >= 30          # the popular templates really formed big clusters

@@ -46,12 +46,20 @@ def run(eng, name, spec, K, bands, rows, steps=2):
 
 
 def main():
-    which = sys.argv[1:] or ["C3", "C5"]
+    which = sys.argv[1:] or ["C3", "C4", "C5"]
     eng = Engine(0)
     if "C3" in which:
         run(eng, "C3-shard", corpus.CorpusSpec(2_500_000, 2048, seed=20240519 + 3, lang="mixed"), 256, 20, 12)
+    if "C4" in which:
+        # one GPU's share of C4 (12.5 M of 100 M documents), cut to 2.5 M here: clusters of 2-50 near-copies (Zipf)
+        run(eng, "C4-shard (2.5M docs)", corpus.CorpusSpec(2_500_000, 2048, seed=20240519 + 4, lang="en", dup_frac=0.15,
+                                                           edit_rates=(0.01, 0.05, 0.1, 0.2), indel_rate=0.005, clusters="zipf50"),
+            128, 9, 13)
     if "C5" in which:
-        spec = corpus.CorpusSpec(250_000, 20480, seed=20240519 + 5, lang="en", dup_frac=0.15)
+        # C5 as SURVEY 8(d) describes it: long documents, boilerplate-heavy ones for bucket skew, edit-rate sweep with
+        # token insertions / deletions
+        spec = corpus.CorpusSpec(250_000, 20480, seed=20240519 + 5, lang="en", dup_frac=0.15, edit_rates=(0.01, 0.05, 0.1, 0.2),
+                                 indel_rate=0.002, boiler_frac=0.05, boiler_share=0.9, n_templates=200)
         for (b, r, K) in [(9, 13, 128), (14, 9, 128), (20, 12, 256)]:
             run(eng, f"C5-shard b{b}xr{r} K{K}", spec, K, b, r)
 
