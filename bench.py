@@ -274,7 +274,11 @@ def main():
     n_local = args.docs
     n_global = n_local * world
     # one global corpus spec; each rank generates its contiguous shard (near-duplicates cross shards)
-    spec = corpus.CorpusSpec(n_global, args.mean_bytes, seed=seed, lang="en")
+    if config_id == 4:      # C4 as SURVEY 8(d) describes it: 15 % near-copies in clusters of 2-50 (Zipf), edit-rate sweep, indels
+        spec = corpus.CorpusSpec(n_global, args.mean_bytes, seed=seed, lang="en", dup_frac=0.15, clusters="zipf50",
+                                 edit_rates=(0.01, 0.05, 0.1, 0.2), indel_rate=0.005)
+    else:
+        spec = corpus.CorpusSpec(n_global, args.mean_bytes, seed=seed, lang="en")
     d0 = rank * n_local
     t_gen = time.time()
     texts, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
@@ -503,7 +507,17 @@ def main():
                                  "DESIGN.md 4.1, profiles/r2_issue/"},
         }
         if use_dist:
-            res["exchange"] = {k: v for k, v in (dist_timings or {}).items()}
+            st = res["stage_ms_per_step_rank0"]
+            ex = dict(dist_timings or {})
+            a2a_ms, ag_ms = st.get("all_to_all"), st.get("all_gather")
+            ex["all_to_all_ms"] = a2a_ms
+            ex["all_gather_ms"] = ag_ms
+            if a2a_ms:
+                ex["all_to_all_gb_per_s_rank0"] = (ex.get("all_to_all_bytes_sent", 0) + ex.get("all_to_all_bytes_received", 0)) / (a2a_ms * 1e6)
+            if ag_ms:
+                ex["all_gather_gb_per_s_rank0"] = ex.get("all_gather_bytes_received", 0) / (ag_ms * 1e6)
+            ex["note"] = "rank 0's figures for the last step; bytes = records x (4 x rows + 8); ms from events on the exchange stream"
+            res["exchange"] = ex
         # HBM-bound stages: SURVEY 8(d)'s algorithmic bytes per document against the 8 TB/s peak
         hbm_alg = {"band_keys": 4 * K + BANDS * 20, "bucket_edges": 2 * BANDS * 20, "components": BANDS * 8 + 4}
         res["hbm_stages"] = {k: {"ms": res["stage_ms_per_step_rank0"].get(k), "algorithmic_bytes_per_doc": v,

@@ -120,16 +120,16 @@ class CorpusSpec:
         self.is_zh = self.is_zh[src]
         self.src, self.is_dup, self.ntok = src, is_dup, ntok
         # per-document substitution rate (as a 32-bit threshold) and boilerplate template (-1: none)
-        rate = np.full(n, edit_rate)
-        if edit_rates:
-            rate = np.asarray(edit_rates, dtype=np.float64)[rng2.integers(0, len(edit_rates), n)]
-        self.rate_thr = np.minimum(rate * 2.0 ** 32, 2.0 ** 32 - 1).astype(np.int64)
-        self.template = np.full(n, -1, dtype=np.int64)
+        rates = np.asarray(edit_rates if edit_rates else (edit_rate,), dtype=np.float64)
+        self.rate_table = np.minimum(rates * 2.0 ** 32, 2.0 ** 32 - 1).astype(np.int64)
+        self.rate_idx = rng2.integers(0, len(rates), n, dtype=np.uint8) if edit_rates else None    # None: one rate for all
+        self.template = None
         if boiler_frac > 0:
+            tpl = np.full(n, -1, dtype=np.int32)
             pick = rng2.random(n) < boiler_frac
             wt = 1.0 / np.arange(1, n_templates + 1)
-            self.template[pick] = rng2.choice(n_templates, int(pick.sum()), p=wt / wt.sum())
-            self.template = self.template[src]          # a near-copy keeps its source's template
+            tpl[pick] = rng2.choice(n_templates, int(pick.sum()), p=wt / wt.sum())
+            self.template = tpl[src]                    # a near-copy keeps its source's template
         self.thr_en = _zipf_thresholds(VOCAB_EN)
         self.thr_zh = _zipf_thresholds(VOCAB_ZH)
 
@@ -163,12 +163,15 @@ def _tokens(spec: CorpusSpec, d0: int, d1: int, device) -> Tuple[torch.Tensor, .
         spos = torch.minimum(pos + shift, nt - 1)
     u_src = _lsr(_h(spec.seed, src, spos), 32)
     u_own = _lsr(_h(spec.seed + 1, doc, pos), 32)
-    thr = torch.from_numpy(spec.rate_thr[d0:d1]).to(device)[doc_local]
+    if spec.rate_idx is None:
+        thr = int(spec.rate_table[0])
+    else:
+        thr = torch.from_numpy(spec.rate_table).to(device)[torch.from_numpy(spec.rate_idx[d0:d1].astype(np.int64)).to(device)][doc_local]
     edit = is_dup & ((_lsr(_h(spec.seed + 2, doc, pos), 32) < thr) | inserted)
     u = torch.where(edit, u_own, u_src)
     if spec.boiler_frac > 0:
         # boilerplate: the first boiler_share of the document's tokens come from its template's stream
-        tpl = torch.from_numpy(spec.template[d0:d1]).to(device)[doc_local]
+        tpl = torch.from_numpy(spec.template[d0:d1].astype(np.int64)).to(device)[doc_local]
         nb = (ntok[doc_local].to(torch.float64) * spec.boiler_share).to(torch.int64)
         in_tpl = (tpl >= 0) & (pos < nb) & ~edit
         u = torch.where(in_tpl, _lsr(_h(spec.seed + 7, tpl, pos), 32), u)
