@@ -115,8 +115,8 @@ def run(args, engine_factory=None) -> dict:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or getattr(args, "distributed", False)
     all_files = hostio.list_files(args.input_dir)
-    lo, hi = (len(all_files) * rank) // world, (len(all_files) * (rank + 1)) // world
-    files = all_files[lo:hi]
+    f_lo, f_hi = (len(all_files) * rank) // world, (len(all_files) * (rank + 1)) // world
+    files = all_files[f_lo:f_hi]
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.time()
@@ -228,8 +228,9 @@ def run(args, engine_factory=None) -> dict:
         kept_rows = None
         if args.write_shards:
             os.makedirs(os.path.join(args.output_dir, "shards"), exist_ok=True)
-            tasks = [(p, os.path.join(args.output_dir, "shards", os.path.basename(p).split(".")[0] + ".jsonl.gz"),
-                      args.id_field, remove_ids) for p in files]
+            # names are derived from ALL input files (every rank computes the same list), so they are unique across ranks
+            out_names = hostio.shard_output_names(all_files)[f_lo:f_hi]
+            tasks = [(p, os.path.join(args.output_dir, "shards", nm), args.id_field, remove_ids) for p, nm in zip(files, out_names)]
             kept_rows = sum(pool.imap_unordered(_write_shard, tasks))
         t3 = time.time()
     finally:

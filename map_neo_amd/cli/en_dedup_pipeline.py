@@ -83,7 +83,8 @@ def run(args) -> dict:
     counts["after_minhash"] = len(ids)
     t.append(time.time())
     # 3. paragraph dedup (PAR:15-30): documents in doc_id order
-    order = sorted(range(len(ids)), key=lambda k: ids[k])
+    from ..hostio import id_order_key
+    order = sorted(range(len(ids)), key=lambda k: id_order_key(ids[k]))
     text, offs = reorder_packed(eng, text, offs, eng.to_device(np.asarray(order, dtype=np.int64)))
     text, offs, docs = exact.paragraph_dedup_packed(eng, text, offs, 20)
     ids = [ids[order[d]] for d in docs.cpu().tolist()]

@@ -39,7 +39,8 @@ def run(args) -> dict:
     c = load_corpus(args.input_dir, args.workers, args.device)
     eng, ids = c["eng"], c["doc_ids"]
     t1 = time.time()
-    order = sorted(range(len(ids)), key=lambda k: ids[k])                  # Window.orderBy(doc_id, pos); stable
+    from ..hostio import id_order_key
+    order = sorted(range(len(ids)), key=lambda k: id_order_key(ids[k]))    # Window.orderBy(doc_id, pos); stable; nulls first
     perm = eng.to_device(np.asarray(order, dtype=np.int64))
     text, offs = reorder_packed(c["eng"], c["text"], c["offs"], perm)
     out_text, out_offs, docs = exact.paragraph_dedup_packed(eng, text, offs, args.min_len)

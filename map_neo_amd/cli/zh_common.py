@@ -73,7 +73,15 @@ def copy_without_lines(src: str, dst: str, drop) -> None:
     copying different files do not queue on the interpreter lock."""
     with open(src, "rb") as f:
         data = f.read()
-    with open(dst, "wb") as fw:
+    # The reference reads plain text only (ZH-1:40, ZH-5:9); the ingest of these commands also accepts gzip'd shards and
+    # numbers their DECOMPRESSED lines, so a gzip'd shard is inflated here, filtered, and written back as gzip -- cutting
+    # byte ranges out of the compressed stream would corrupt the file.
+    opener = open
+    if data[:2] == b"\x1f\x8b":
+        import gzip
+        data = gzip.decompress(data)
+        opener = gzip.open
+    with opener(dst, "wb") as fw:
         if not drop:
             fw.write(data)
             return

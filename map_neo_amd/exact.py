@@ -172,7 +172,8 @@ def paragraph_dedup(eng: Engine, rows: Sequence[Tuple[object, Optional[str]]], m
                     key_bits: int = 64, fused: bool = True) -> List[Tuple[object, str]]:
     """(id, text) per surviving document, sorted by id.  Ids must be unique and mutually comparable
     (the reference would merge the rows of a repeated id, PAR:26)."""
-    rows = sorted(((rid, c) for rid, c in rows if c is not None), key=lambda r: r[0])
+    from .hostio import id_order_key
+    rows = sorted(((rid, c) for rid, c in rows if c is not None), key=lambda r: id_order_key(r[0]))
     if not rows:
         return []
     buf, offs = pack_texts([c for _, c in rows])

@@ -23,6 +23,36 @@ def list_files(directory: str) -> List[str]:
     return out
 
 
+def id_order_key(v):
+    """Total order over the values a doc_id column can hold (JSON scalars and None), in the spirit of Spark's
+    ascending sort: nulls first, then booleans / numbers by value, then strings; anything else by its JSON text.
+    Plain `sorted` raises TypeError on a missing (None) id or on mixed int / str ids."""
+    if v is None:
+        return (0, 0, "")
+    if isinstance(v, (bool, int, float)):
+        return (1, v, "")
+    if isinstance(v, str):
+        return (2, 0, v)
+    import json
+    return (3, 0, json.dumps(v, sort_keys=True, default=str))
+
+
+def shard_output_names(paths, suffix: str = ".jsonl.gz"):
+    """Output file name for every input shard: the input's base name with only its format suffix replaced
+    (.jsonl / .json / .parquet / .pq / .txt, optionally followed by .gz), so that `c4-train.00000-of-01024.json.gz` and
+    `c4-train.00001-of-01024.json.gz` -- or `data.0.jsonl` and `data.1.jsonl` -- keep distinct names.  Names that
+    still coincide (`a.jsonl` and `a.jsonl.gz`, equal names in different directories) get their position in `paths`
+    as a prefix.  The result is unique by construction."""
+    import re
+    stems = [re.sub(r"(\.(jsonl|json|parquet|pq|txt))?(\.gz)?$", "", os.path.basename(p), flags=re.I) or os.path.basename(p) for p in paths]
+    seen = {}
+    for s in stems:
+        seen[s] = seen.get(s, 0) + 1
+    names = [(s if seen[s] == 1 else "%05d_%s" % (i, s)) + suffix for i, s in enumerate(stems)]
+    assert len(set(names)) == len(names)
+    return names
+
+
 def open_text(path: str, mode: str = "rt"):
     if path.endswith(".gz"):
         return gzip.open(path, mode, encoding="utf8", newline="\n") if "t" in mode else gzip.open(path, mode)

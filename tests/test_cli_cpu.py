@@ -95,3 +95,37 @@ def test_copy_without_lines_equals_line_loop(tmp_path):
             dst = tmp_path / "dst.jsonl"
             Z.copy_without_lines(str(src), str(dst), drop)
             assert dst.read_bytes() == exp, (data, drop)
+
+
+def test_shard_output_names_are_unique_and_keep_the_dotted_part():
+    """`basename.split(".")[0]` mapped c4-train.00000-of-01024.json.gz and ...00001... to one output file"""
+    names = hostio.shard_output_names(["/d/c4-train.00000-of-01024.json.gz", "/d/c4-train.00001-of-01024.json.gz", "/d/data.0.jsonl",
+                                       "/d/data.1.jsonl", "/d/a.jsonl", "/d/a.jsonl.gz", "/e/a.parquet", "/d/plain", "/d/x.PQ"])
+    assert names[:4] == ["c4-train.00000-of-01024.jsonl.gz", "c4-train.00001-of-01024.jsonl.gz", "data.0.jsonl.gz", "data.1.jsonl.gz"]
+    assert names[4:7] == ["00004_a.jsonl.gz", "00005_a.jsonl.gz", "00006_a.jsonl.gz"] and names[7:] == ["plain.jsonl.gz", "x.jsonl.gz"]
+    assert len(set(names)) == len(names)
+
+
+def test_id_order_key_is_total():
+    ids = ["b", 3, None, "a", 2.5, None, True, {"k": 1}, "10", 10]
+    got = sorted(ids, key=hostio.id_order_key)
+    assert got[:2] == [None, None] and got[2:6] == [True, 2.5, 3, 10] and got[6:9] == ["10", "a", "b"] and got[9] == {"k": 1}
+
+
+def test_copy_without_lines_handles_gzip_shards(tmp_path):
+    """line indices refer to the decompressed text; a gzip'd shard is inflated, filtered and written as gzip"""
+    import gzip
+    from map_neo_amd.cli import zh_common as Z
+    lines = [("line %d" % i).encode() + b"\n" for i in range(50)]
+    lines[-1] = lines[-1][:-1]                      # last line without a newline
+    src_gz, src_plain = tmp_path / "s.jsonl.gz", tmp_path / "s.jsonl"
+    src_gz.write_bytes(gzip.compress(b"".join(lines)))
+    src_plain.write_bytes(b"".join(lines))
+    drop = {0, 7, 8, 49, 100}
+    Z.copy_without_lines(str(src_gz), str(tmp_path / "o.jsonl.gz"), drop)
+    Z.copy_without_lines(str(src_plain), str(tmp_path / "o.jsonl"), drop)
+    want = b"".join(l for i, l in enumerate(lines) if i not in drop)
+    assert (tmp_path / "o.jsonl").read_bytes() == want
+    assert gzip.decompress((tmp_path / "o.jsonl.gz").read_bytes()) == want
+    Z.copy_without_lines(str(src_gz), str(tmp_path / "all.gz"), set())
+    assert gzip.decompress((tmp_path / "all.gz").read_bytes()) == b"".join(lines)

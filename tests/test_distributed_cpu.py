@@ -89,7 +89,8 @@ def test_stage_cli_two_ranks_gloo(tmp_path, mini_docs, world):
     inp.mkdir()
     bounds = [0, 40, 95, 150, n]
     for f in range(4):
-        with open(inp / f"s{f}.jsonl", "w", encoding="utf8") as fh:
+        # dotted shard names that differ only after the first dot (they used to collapse to ONE output file)
+        with open(inp / f"part.{f:05d}-of-00004.jsonl", "w", encoding="utf8") as fh:
             for i in range(bounds[f], bounds[f + 1]):
                 fh.write(json.dumps({"doc_id": ids[i], "raw_content": mini_docs[i]}, ensure_ascii=False) + "\n")
     script = tmp_path / "cli_worker.py"
@@ -117,6 +118,7 @@ def test_stage_cli_two_ranks_gloo(tmp_path, mini_docs, world):
     assert set(kept) == set(ids) - exp_removed and len(kept) + len(exp_removed) == n
     got = {c["doc_id"]: c["cluster"] for c in map(json.loads, open(out / "clusters.jsonl", encoding="utf8"))}
     assert got == exp_cluster
+    assert sorted(os.listdir(out / "shards")) == [f"part.{f:05d}-of-00004.jsonl.gz" for f in range(4)]
     rows = [json.loads(l) for p in sorted(os.listdir(out / "shards")) for l in gzip.open(out / "shards" / p, "rt", encoding="utf8")]
     assert sorted(r["doc_id"] for r in rows) == sorted(set(ids) - exp_removed)
     s = json.load(open(out / "summary.json"))
