@@ -51,6 +51,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
+    p.add_argument("--checkpoint_dir", default=None,
+                   help="write signatures / edges / labels + manifest.json there (map_neo_amd/checkpoint.py; single process)")
+    p.add_argument("--resume_from", choices=["signatures", "edges", "labels"], default=None,
+                   help="start from that artifact of --checkpoint_dir instead of parsing and hashing the input")
     return p
 
 
@@ -127,9 +131,15 @@ def run(args, engine_factory=None) -> dict:
         pool = ThreadPool(n_workers)
     else:
         pool = mp.get_context("fork").Pool(n_workers)                      # forked before this process touches the GPU
+    ckpt_dir, resume = getattr(args, "checkpoint_dir", None), getattr(args, "resume_from", None)
+    if (ckpt_dir or resume) and distributed:
+        raise SystemExit("--checkpoint_dir / --resume_from: single-process runs only")
+    if resume and not ckpt_dir:
+        raise SystemExit("--resume_from needs --checkpoint_dir")
     try:
-        parsed = pool.imap(_parse_shard, [(p, args.id_field, args.content_field, args.normalize) for p in files])
+        parsed = pool.imap(_parse_shard, [(p, args.id_field, args.content_field, args.normalize) for p in ([] if resume else files)])
         import torch
+        from .. import checkpoint as ckpt
 
         from ..dedup import cluster_distributed, cluster_local
         from ..minhash import as_u32, padded_size
@@ -177,11 +187,38 @@ def run(args, engine_factory=None) -> dict:
             sigs.append(sig)
             cand_ids.extend(ids[i] for i in cand.tolist())
         t1 = time.time()
+        state = None
+        if resume:
+            state = ckpt.load(ckpt_dir, resume, ckpt.params_of(args))
+            cand_ids = state["doc_ids"]
+            all_ids, any_synth = state["manifest"]["extra"]["all_ids"], state["manifest"]["extra"]["any_synth"]
         n = len(cand_ids)
-        sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
+        if resume:
+            sig = eng.to_device(state["signatures"].reshape(-1)).view(n, args.num_perm) if resume == "signatures" else None
+        else:
+            sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
+        ck_extra = {"all_ids": all_ids, "any_synth": any_synth}
+        if ckpt_dir and not resume:
+            ckpt.save(ckpt_dir, ckpt.params_of(args), cand_ids, signatures=as_u32(sig).reshape(n, args.num_perm), extra=ck_extra)
         if not distributed:
             doc_base, n_global = 0, n
-            labels = as_u32(cluster_local(eng, sig, args.bands, args.rows)["labels"])
+            if resume == "labels":
+                labels = state["labels"]
+            elif resume == "edges":
+                e = state["edges"]
+                lab = eng.components_init(n)
+                if len(e):
+                    eng.components_union(lab, eng.to_device(np.ascontiguousarray(e[:, 0])), eng.to_device(np.ascontiguousarray(e[:, 1])))
+                eng.components_finish(lab)
+                labels = as_u32(lab).reshape(n)
+            else:
+                out = cluster_local(eng, sig, args.bands, args.rows)
+                labels = as_u32(out["labels"]).reshape(n)
+                if ckpt_dir:
+                    edges = np.ascontiguousarray(np.stack([as_u32(out["edge_u"]), as_u32(out["edge_v"])], axis=1))
+                    rewrite = resume == "signatures" and state["manifest"]["params"] != ckpt.params_of(args)
+                    ckpt.save(ckpt_dir, ckpt.params_of(args), cand_ids, signatures=state["signatures"] if rewrite else None,
+                              edges=edges, labels=labels, extra=ck_extra)
         else:
             counts = [None] * world
             dist.all_gather_object(counts, (n, any_synth))

@@ -1,8 +1,10 @@
 """CPU suite: host logic of the drop-in commands -- flags match the reference's scripts,
 text normalisation matches the oracle, ZH-4 / ZH-5 bookkeeping (no GPU involved)."""
+import json
 import os
 import pickle
 
+import numpy as np
 import pytest
 
 from map_neo_amd import hostio
@@ -129,3 +131,60 @@ def test_copy_without_lines_handles_gzip_shards(tmp_path):
     assert gzip.decompress((tmp_path / "o.jsonl.gz").read_bytes()) == want
     Z.copy_without_lines(str(src_gz), str(tmp_path / "all.gz"), set())
     assert gzip.decompress((tmp_path / "all.gz").read_bytes()) == b"".join(lines)
+
+
+def test_checkpoint_manifest_roundtrip_and_refusals(tmp_path):
+    from map_neo_amd import checkpoint as C
+    d = str(tmp_path / "ck")
+    p = {"width": 13, "ngram_unit": "char", "num_perm": 4, "bands": 2, "rows": 2, "seed": 1}
+    ids = ["a", "b", "c"]
+    sig = np.arange(12, dtype=np.uint32).reshape(3, 4)
+    C.save(d, p, ids, signatures=sig, extra={"n_rows": 5})
+    man = C.save(d, p, ids, edges=np.array([[1, 0]], np.uint32), labels=np.array([0, 0, 2], np.uint32))
+    assert sorted(man["artifacts"]) == ["doc_ids", "edges", "labels", "signatures"]            # earlier artifacts stay listed
+    assert (C.load(d, "signatures", p)["signatures"] == sig).all() and C.load(d, "edges", p)["doc_ids"] == ids
+    assert C.load(d, "labels", p)["labels"].tolist() == [0, 0, 2]
+    with pytest.raises(C.CheckpointError, match="other parameters"):
+        C.load(d, "labels", dict(p, bands=3))                   # labels depend on (bands, rows) ...
+    assert C.load(d, "signatures", dict(p, bands=3))["doc_ids"] == ids          # ... signatures do not
+    with pytest.raises(C.CheckpointError, match="other parameters"):
+        C.load(d, "signatures", dict(p, width=5))
+    with pytest.raises(C.CheckpointError, match="nothing to resume"):
+        C.load(str(tmp_path / "none"), "signatures", p)
+    os.remove(os.path.join(d, "edges.npy"))
+    man = C.save(d, p, ids)
+    assert "edges" not in man["artifacts"]                      # a listed artifact whose file is gone is dropped
+
+
+def test_stage_cli_checkpoint_and_resume(tmp_path, mini_docs):
+    """cli/dedup with the oracle-backed CPU backend: --checkpoint_dir, then --resume_from signatures | edges | labels --
+    identical outputs every time (checkpoint / resume)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_backend import OracleBackend
+    from map_neo_amd.cli import dedup as stage
+    n = len(mini_docs)
+    inp = tmp_path / "in"
+    inp.mkdir()
+    with open(inp / "a.jsonl", "w", encoding="utf8") as fh:
+        for i in range(n):
+            fh.write(json.dumps({"doc_id": f"id{(i * 37) % n:04d}", "raw_content": mini_docs[i]}, ensure_ascii=False) + "\n")
+    base = ["--input_dir", str(inp), "--normalize", "none", "--workers", "1", "--checkpoint_dir", str(tmp_path / "ck")]
+
+    def run(out, extra):
+        stage.run(stage.build_parser().parse_args(base + ["--output_dir", str(tmp_path / out)] + extra), engine_factory=lambda d: OracleBackend())
+        return {f: open(tmp_path / out / f, encoding="utf8").read() for f in ("clusters.jsonl", "kept_ids.txt", "removed_ids.txt")}
+
+    ref = run("o0", [])
+    assert ref["removed_ids.txt"].strip()
+    man = json.load(open(tmp_path / "ck" / "manifest.json"))
+    assert sorted(man["artifacts"]) == ["doc_ids", "edges", "labels", "signatures"]
+    for st in ("signatures", "edges", "labels"):
+        assert run("o_" + st, ["--resume_from", st]) == ref, st
+    with pytest.raises(Exception, match="other parameters"):
+        run("o_bad", ["--resume_from", "labels", "--bands", "14", "--rows", "9"])
+    # signatures can be reused for another (bands, rows): equals a fresh run with those parameters
+    swept = run("o_sweep", ["--resume_from", "signatures", "--bands", "14", "--rows", "9"])
+    fresh = stage.run(stage.build_parser().parse_args(["--input_dir", str(inp), "--normalize", "none", "--workers", "1", "--bands", "14", "--rows", "9",
+                                                       "--output_dir", str(tmp_path / "o_fresh")]), engine_factory=lambda d: OracleBackend())
+    assert swept["removed_ids.txt"] == open(tmp_path / "o_fresh" / "removed_ids.txt").read() and fresh["n_removed_ids"] > 0

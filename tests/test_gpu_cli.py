@@ -58,6 +58,23 @@ def test_en_cli_end_to_end(tmp_path, mini_docs, capsys):
     assert inter_ids == [r["doc_id"] for r in rows if r["raw_content"] is not None]     # input order
     row_of = {d: k for k, d in enumerate(ids)}
     assert (sig == exp["signatures"][[row_of[d] for d in inter_ids]]).all()
+    # checkpoint manifest + resume: every artifact is named, and restarting from each gives identical outputs
+    man = json.load(open(tmp_path / "inter" / "manifest.json"))
+    assert sorted(man["artifacts"]) == ["doc_ids", "edges", "labels", "signatures"] and man["params"]["bands"] == 9
+
+    def parts(d):
+        return [gzip.open(tmp_path / d / p, "rb").read() for p in sorted(os.listdir(tmp_path / d))]
+
+    ref_parts = parts("out")
+    for st in ("signatures", "edges", "labels"):
+        minhashLsh.main(["--input_dir", str(inp), "--inter_dir", str(tmp_path / "inter"), "--output_dir", str(tmp_path / ("out_" + st)),
+                         "--workers", "2", "--resume_from", st])
+        assert parts("out_" + st) == ref_parts, st
+        assert f"the number of doc need to be remove is  {len(exp_removed)}" in capsys.readouterr().out
+    from map_neo_amd.checkpoint import CheckpointError
+    with pytest.raises(CheckpointError, match="other parameters"):
+        minhashLsh.main(["--input_dir", str(inp), "--inter_dir", str(tmp_path / "inter"), "--output_dir", str(tmp_path / "bad"),
+                         "--resume_from", "edges", "--bands", "14", "--rows", "9"])
 
 
 def _zh_files(tmp_path, mini_docs):
