@@ -419,7 +419,7 @@ def main():
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", cand, "summary.json")))
                 if pm["workload"]["text_bytes_per_gpu"] == text_bytes and pm["workload"]["docs_per_gpu"] == n_local:
-                    k = pm["kernels"]["sig_kernel<2, false>"]
+                    k = pm["kernels"].get("sig_kernel<2, false, false>") or pm["kernels"]["sig_kernel<2, false>"]
                     traffic, traffic_source = k["fetch_bytes"] + k["write_bytes"], "profiles/%s/summary.json" % cand
                     break
             except Exception:
