@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--docs", type=int, default=None,
                     help="documents per GPU (default: 1 000 000 = C2 at N=1; 12 500 000 = one GPU's share of C4 at N>1)")
     ap.add_argument("--mean-bytes", type=int, default=2048)
+    ap.add_argument("--corpus-config", choices=["auto", "2", "4"], default="auto",
+                    help="synthetic corpus: 2 = C2's generator settings, 4 = C4's (Zipf clusters of 2-50, edit-rate sweep, token "
+                         "insert/delete); auto = 4 when the job holds >= 50 M documents (the N > 1 default), else 2")
     ap.add_argument("--cpu-sample-docs", type=int, default=10000,
                     help="documents of the CPU baseline (default: BASELINE.json configs[0] in full = 10 000 docs)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -238,7 +241,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.docs is None:
         args.docs = 1_000_000 if world == 1 else 12_500_000
-    config_id = 2 if args.docs * world < 50_000_000 else 4
+    config_id = int(args.corpus_config) if args.corpus_config != "auto" else (2 if args.docs * world < 50_000_000 else 4)
     seed = 20240519 + config_id                   # config id
 
     cpu = None

@@ -528,7 +528,8 @@ def test_bench_script_multi_rank_rehearsal():
     env = dict(os.environ, MDD_BENCH_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
     port = str(29850 + os.getpid() % 100)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-                        "--master-port", port, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--docs", "50000"],
+                        "--master-port", port, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--docs", "50000",
+                        "--corpus-config", "4"],          # the corpus settings the driver's N > 1 runs get by default
                        capture_output=True, text=True, timeout=120, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -536,11 +537,16 @@ def test_bench_script_multi_rank_rehearsal():
     multi = json.loads(lines[0])
     assert multi["n_gpus"] == 4 and multi["config"]["global_docs"] == 200000 and multi["scaling"] == "weak"
     assert multi["vs_baseline"] is None and "cpu_baseline" not in multi
-    r1 = subprocess.run([sys.executable, "bench.py", "--docs", "200000", "--no-cpu", "--no-pcie", "--no-stages", "--steps", "1", "--warmup", "0"],
+    ex = multi["exchange"]
+    assert ex["transport"] == "torch.distributed" and ex["records_sent"] == 50000 * 9 and ex["all_to_all_ms"] > 0 and ex["all_gather_ms"] > 0
+    assert ex["all_to_all_bytes_sent"] == 50000 * 9 * 60 and multi["config"]["workload"].startswith("C4 share")
+    r1 = subprocess.run([sys.executable, "bench.py", "--docs", "200000", "--no-cpu", "--no-pcie", "--no-stages", "--steps", "1", "--warmup", "0",
+                         "--corpus-config", "4"],
                         capture_output=True, text=True, timeout=120, env=dict(os.environ), cwd=root)
     assert r1.returncode == 0, r1.stderr[-3000:]
     single = json.loads(r1.stdout.strip().splitlines()[-1])
-    assert multi["n_removed"] == single["n_removed"] > 0.5 * single["n_injected_duplicates"]
+    # (LSH at ~0.8 Jaccard catches the lightly edited copies of C4's edit-rate sweep, not the 10-20 % ones)
+    assert multi["n_removed"] == single["n_removed"] > 0.2 * single["n_injected_duplicates"]
 
 
 def test_stage_cli_multi_rank_rehearsal(tmp_path, mini_docs):
