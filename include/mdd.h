@@ -301,6 +301,20 @@ int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
  * 1 <= window <= 128; text 4-byte aligned with MDD_TEXT_PAD spare bytes, text_bytes < 2^40. */
 int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                     int window, int part, int n_parts, uint64_t* table, uint64_t tab_size, uint8_t* dup);
+/*   mark_sorted: the same marks as `mark`, computed without random atomics on a big table (mdd_substr_part.hip): every
+ *          window becomes an 8-byte entry, two 2048-way partition passes (streaming traffic only) sort the entries into
+ *          2^22 leaves by content key, and one workgroup per leaf groups its ~500 windows in an LDS table (tag matches
+ *          confirmed on the bytes, so the result is exact).  About twice as fast as `mark` on corpora of millions of
+ *          documents.  text_bytes < 2^36.  Workspaces (caller-allocated, contents irrelevant):
+ *            ent_a, ent_b  u64[ent_cap] each, ent_cap >= 1.05 x windows of the pass + 2048 x 28 x CUs + 12288
+ *            d1_ws         u16[ent_cap]
+ *            ws            u64[ws_words], ws_words >= MDD_SUBSTR_SORTED_WS_WORDS
+ *          part / n_parts as for `mark` (windows are split by content key; part 0 clears dup).  An entry array that is
+ *          too small, or more than 768 distinct windows in one leaf, is counted and reported by mdd_substr_check. */
+#define MDD_SUBSTR_SORTED_WS_WORDS 10492939ull
+int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                           int window, int part, int n_parts, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap,
+                           uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup);
 /*   check: mark is asynchronous and cannot validate tab_size against the (device-side) number of windows.  A window
  *          that finds neither its content nor a free slot is counted on the device; mdd_substr_check synchronises
  *          the stream, stores that count in *n_overflow_host (HOST, may be NULL), clears it and returns

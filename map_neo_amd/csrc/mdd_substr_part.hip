@@ -1,0 +1,757 @@
+// Exact substring dedup, bandwidth-bound formulation (same reference lines as mdd_substr.hip:
+// exact_substr_dedup.py:34-47 -- hash every window, group, all occurrences but the first are repeats).
+//
+// mdd_substr.hip's win_kernel puts one random 8-byte atomic per window on a table far larger than any cache; such
+// atomics execute at the memory side (~17.5 G/s on this chip, 86 bytes written per atomic: 184 GB for C2's 2.13 G
+// windows).  Here the windows are SORTED INTO LEAVES first and grouped in LDS:
+//   emit      every window -> one 8-byte entry [d2:11 | tag:17 | position:36] appended to a flat array (each wave
+//             reserves chunks of it); d1 = key bits 63..53 goes to a parallel u16 array and is counted in LDS
+//   scatter<1>  entries -> their d1 partition (2048 partitions), tiles sorted by bin in LDS before they are written
+//   count2 / scatter<2>   the same inside every partition on d2 = key bits 52..42  ->  2^22 leaves of ~500 windows
+//   leaf      one wave per leaf: an LDS table of 8-byte entries (tag | lowest position); a tag match is confirmed by
+//             COMPARING THE BYTES of the two windows (so the result is exact), the later window of a matching pair is
+//             marked.  Leaves of any size work (boilerplate puts millions of identical windows into one leaf: they share
+//             one LDS slot); more than LEAF_SLOTS * 3/4 DISTINCT windows in one leaf (hash adversary) raise the overflow
+//             count that mdd_substr_check reports.
+// Equal 64-bit keys land in the same leaf, so every pair of identical windows meets in one LDS table.
+#include "mdd_shingle.h"
+
+namespace {
+
+constexpr int D1_BITS = 11, BINS1 = 1 << D1_BITS;  // level-1 partitions
+constexpr int D2_BITS = 11, BINS2 = 1 << D2_BITS;  // leaves per partition
+constexpr int TAG_BITS = 17;
+constexpr int POS_BITS = 36;  // text_bytes < 64 GiB per call
+static_assert(D2_BITS + TAG_BITS + POS_BITS == 64, "entry layout");
+constexpr uint64_t POS_M = (1ULL << POS_BITS) - 1;
+constexpr uint64_t ENT_INVALID = ~0ULL;
+constexpr uint16_t D1_INVALID = 0xFFFFu;
+constexpr uint32_t EMIT_CHUNK = 2048;  // entries a wave reserves at a time
+constexpr int XCDS = 8;
+constexpr int LEAF_SLOTS = 1024;  // LDS table entries per leaf (one wave per leaf): up to 768 DISTINCT windows
+
+// 64-bit content key of the L bytes at byte offset s from tv.docw.  Equal bytes give equal keys; that is all exactness
+// needs (the leaves compare bytes), the rest is balance.  The per-dword step is add / rotate / xor only -- v_mul_lo_u32
+// issues at a quarter of the rate, so the multiplies (mix64) come once per window, not once per dword as in win_kernel's
+// window_key -- and the dwords are loaded eight at a time (a loop of single dependent loads left the kernel waiting on
+// the L1 round trip thirteen times per window).
+__device__ __forceinline__ uint64_t wkey(const TextView& tv, uint32_t s, uint32_t L) {
+    const uint32_t* src = tv.docw + (s >> 2);
+    const uint32_t sh = s & 3u;
+    uint32_t h1 = 0x9E3779B9u ^ L, h2 = 0x85EBCA6Bu;
+    uint32_t lo = src[0];
+    const uint32_t nd = (L + 3u) >> 2;
+    for (uint32_t k0 = 0; k0 < nd; k0 += 8) {
+        uint32_t r[8];  // (at most 32 bytes past the window: inside MDD_TEXT_PAD)
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = src[k0 + 1 + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t k = k0 + j;
+            if (k < nd) {
+                uint32_t w = __builtin_amdgcn_alignbyte(r[j], lo, sh);
+                const uint32_t rem = L - 4u * k;
+                if (rem < 4u) w &= 0xFFFFFFFFu >> (8u * (4u - rem));
+                h1 = __builtin_amdgcn_alignbit(h1, h1, 27) + w;         // rotl 5
+                h2 = (__builtin_amdgcn_alignbit(h2, h2, 19) ^ w) + h1;  // rotl 13
+                lo = r[j];
+            }
+        }
+    }
+    return mix64(((uint64_t)h1 << 32) | h2);
+}
+__device__ __forceinline__ uint32_t d1_of(uint64_t key) { return (uint32_t)(key >> (64 - D1_BITS)); }
+__device__ __forceinline__ uint64_t entry_of(uint64_t key, uint64_t pos) {  // [d2:11 | tag:17 | pos:36] = key bits 52..25, position
+    return (((key >> (64 - D1_BITS - D2_BITS - TAG_BITS)) & ((1ULL << (D2_BITS + TAG_BITS)) - 1)) << POS_BITS) | pos;
+}
+__device__ __forceinline__ uint32_t d2_of(uint64_t e) { return (uint32_t)(e >> (POS_BITS + TAG_BITS)); }
+
+struct EmitArgs {
+    const uint8_t* text;
+    uint64_t text_bytes;
+    const uint64_t* offsets;
+    uint64_t n_docs;
+    uint32_t window, seg_bytes;
+    const uint64_t* items;
+    const uint64_t* n_items;
+    uint64_t max_items;
+    unsigned long long* work_counter;
+    uint64_t* ent;
+    uint16_t* d1;               // level-1 digit of every entry (the entry itself has no room for it)
+    uint64_t ent_cap;
+    unsigned long long* n_ent;  // entries handed out so far (whole chunks)
+    unsigned int* hist1;        // [BINS1]
+    unsigned long long* overflow;
+    uint32_t part, n_parts;
+};
+
+// persistent waves pulling documents (then queued segments of long documents) from one counter, four waves per workgroup
+// sharing the LDS histogram of d1; every wave leaves once the counter passes `total`
+constexpr int EMIT_WAVES = 4;
+__global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
+    __shared__ WaveLds lds_all[EMIT_WAVES];
+    __shared__ unsigned int h1[BINS1];
+    WaveLds& lds = lds_all[threadIdx.x >> 6];
+    const uint32_t lane = lane_id();
+    for (int i = threadIdx.x; i < BINS1; i += 64 * EMIT_WAVES) h1[i] = 0;
+    __syncthreads();
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(A.text);
+    const uint64_t extra = *A.n_items;
+    const uint64_t total = A.n_docs + (extra < A.max_items ? extra : A.max_items);
+    auto fetch = [&]() -> uint64_t {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(A.work_counter, 1ull);
+        uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t chunk_pos = 0, chunk_end = 0;  // this wave's current chunk of the entry array (wave-uniform)
+    uint64_t item = fetch();
+    while (item < total) {
+        uint64_t next_item = fetch();
+        uint64_t d = item;
+        uint32_t seg = 0;
+        if (d >= A.n_docs) {
+            uint64_t it = A.items[d - A.n_docs];
+            d = it >> 24;
+            seg = (uint32_t)it & 0xFFFFFFu;
+        }
+        uint64_t beg, end;
+        doc_range(A.offsets, d, A.text_bytes, beg, end);
+        const uint32_t len = (uint32_t)(end - beg);
+        const bool split = len > A.seg_bytes;
+        const uint32_t seg_beg = seg * A.seg_bytes;
+        const uint32_t seg_end = (uint64_t)seg_beg + A.seg_bytes < len ? seg_beg + A.seg_bytes : len;
+        TextView tv;
+        tv.docw = tw + (beg >> 2);
+        const uint32_t boff = (uint32_t)beg & 3u;
+        const bool ascii = segment_is_ascii(tv, boff, len, seg_beg, seg_end, A.window, lane);
+        for_each_round(lds, A.text, beg, len, tv, boff, MDD_UNIT_CHAR, A.window, ascii, split, seg_beg, seg_end, lane,
+                       [&](uint32_t s, uint32_t L, uint32_t nvalid, uint32_t) {
+                           const uint32_t sb = s - boff;
+                           // SUB:38 range(len(text) - duplicate_len): the window that ends with the document is never hashed
+                           bool on = lane < nvalid && sb + L < len;
+                           uint64_t key = 0;
+                           if (on) {
+                               key = wkey(tv, s, L);
+                               if (A.n_parts > 1 && (uint32_t)((key & 0x3FFFu) % A.n_parts) != A.part) on = false;
+                           }
+                           const uint64_t bal = __ballot(on);
+                           const uint32_t cnt = (uint32_t)__popcll(bal);
+                           if (cnt == 0) return;
+                           if (chunk_pos + cnt > chunk_end) {  // not enough room left: void the rest (< 64 entries) and take a new chunk
+                               if (chunk_pos + lane < chunk_end && chunk_pos + lane < A.ent_cap) {
+                                   A.ent[chunk_pos + lane] = ENT_INVALID;
+                                   A.d1[chunk_pos + lane] = D1_INVALID;
+                               }
+                               unsigned long long v = 0;
+                               if (lane == 0) v = atomicAdd(A.n_ent, (unsigned long long)EMIT_CHUNK);
+                               uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+                               chunk_pos = ((uint64_t)hi << 32) | lo;
+                               chunk_end = chunk_pos + EMIT_CHUNK;
+                           }
+                           if (on) {
+                               uint64_t o = chunk_pos + below(bal);
+                               if (o < A.ent_cap) {
+                                   A.ent[o] = entry_of(key, beg + sb);
+                                   A.d1[o] = (uint16_t)d1_of(key);
+                                   atomicAdd(&h1[d1_of(key)], 1u);
+                               } else if (below(bal) == 0) {
+                                   atomicAdd(A.overflow, 1ull);  // entry array too small (caller's contract): reported by mdd_substr_check
+                               }
+                           }
+                           chunk_pos += cnt;
+                       });
+        item = next_item;
+    }
+    for (uint64_t i = chunk_pos + lane; i < chunk_end && i < A.ent_cap; i += 64) {  // void what is left of the last chunk
+        A.ent[i] = ENT_INVALID;
+        A.d1[i] = D1_INVALID;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS1; i += 64 * EMIT_WAVES)
+        if (h1[i]) atomicAdd(&A.hist1[i], h1[i]);
+}
+
+// exclusive scan of n u32 counts -> u64 offsets[n+1] in three small launches: per-block sums (coalesced), scan of the
+// block sums (one workgroup), per-block exclusive scan
+constexpr int SCAN_BLOCK = 4096;  // counts per workgroup of 256 threads
+__global__ void __launch_bounds__(256) scan_sums_kernel(const unsigned int* cnt, uint64_t n, uint64_t* sums) {
+    __shared__ uint64_t red[256];
+    uint64_t lo = (uint64_t)blockIdx.x * SCAN_BLOCK, s = 0;
+    for (int k = 0; k < SCAN_BLOCK / 256; k++) {
+        uint64_t i = lo + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) s += cnt[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(1024) scan_top_kernel(uint64_t* sums, uint64_t nb, uint64_t* total_out) {  // nb <= 1024
+    __shared__ uint64_t v[1024];
+    v[threadIdx.x] = threadIdx.x < nb ? sums[threadIdx.x] : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t acc = 0;
+        for (uint64_t t = 0; t < nb; t++) {
+            uint64_t x = v[t];
+            v[t] = acc;
+            acc += x;
+        }
+        *total_out = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < nb) sums[threadIdx.x] = v[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) scan_apply_kernel(const unsigned int* cnt, uint64_t n, const uint64_t* sums, uint64_t* off) {
+    __shared__ uint64_t tsum[256];
+    const uint64_t lo = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * (SCAN_BLOCK / 256);
+    uint32_t c[SCAN_BLOCK / 256];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_BLOCK / 256; k++) {
+        c[k] = lo + k < n ? cnt[lo + k] : 0u;
+        s += c[k];
+    }
+    tsum[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t acc = sums[blockIdx.x];
+        for (int t = 0; t < 256; t++) {
+            uint64_t x = tsum[t];
+            tsum[t] = acc;
+            acc += x;
+        }
+    }
+    __syncthreads();
+    s = tsum[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_BLOCK / 256; k++) {
+        if (lo + k < n) off[lo + k] = s;
+        s += c[k];
+    }
+}
+// sums: scratch of ceil(n / SCAN_BLOCK) <= 1024 words
+static int exclusive_scan(hipStream_t st, const unsigned int* cnt, uint64_t n, uint64_t* off, uint64_t* sums) {
+    unsigned nb = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, st, cnt, n, sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, sums, (uint64_t)nb, off + n);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, cnt, n, sums, off);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+// ---- the two scatter levels -------------------------------------------------------------------------------------
+// A scatter that stores each entry straight from the thread that loaded it issues 64 different cache lines per store
+// instruction; the texture path takes ~5 cycles per line, which made 2.1 G stores cost 20 ms whatever the tile shape.
+// So a tile is SORTED BY BIN IN LDS first (rank from an LDS counter, block scan of the counts, ONE reservation per
+// non-empty bin and tile) and written out in sorted order: consecutive lanes hold consecutive entries of a bin's run and
+// a store instruction touches few lines.  What then bounds a level is the number of RUNS: a run is a random DRAM access,
+// and the chip sustains ~17.5 G of those per second (the same figure as its random atomics).
+//   level 1: 2048 bins, tiles of 12288 -> runs of 6 entries scattered over the whole entry array (20 ms on C2)
+//   level 2: 2048 bins, tiles of 16384 -> runs of 8 entries, but inside one partition (8 MB), where the XCD's L2 merges
+//            them into full lines (9 ms): tiles never straddle a partition (tile_off = running sum of ceil(size_p / 16384)) and
+//            workgroup b takes tile (b % 8) * ceil(T / 8) + b / 8, so the workgroups of one XCD (b % 8) walk through one
+//            contiguous eighth of the partitions and all stores into a partition pass through the same L2.
+// (Tried and dropped: 1024 + 4096 bins -- level 1 16 ms, level 2 18 ms; per-XCD output sub-streams at level 1 -- no gain, 8 x the open pages; reservations per 8 tiles
+// from a histogram pre-pass -- fewer atomics, but a bin's lines then fill over 8 tiles' time and leave the L2 half-written.)
+constexpr int SC_THREADS = 1024;
+template <int LEVEL>
+struct ScatterLds {
+    static constexpr int BINS = LEVEL == 1 ? BINS1 : BINS2;
+    static constexpr int N = LEVEL == 1 ? 12288 : 16384;  // entries per tile
+    uint64_t sorted[N];
+    uint16_t sbin[LEVEL == 1 ? N : 1];  // level 1: the entry does not carry d1, its bin is staged beside it
+    unsigned int start[BINS];           // counts, then exclusive starts inside the tile
+    unsigned long long gbase[BINS];     // global index of the bin's run minus its start inside the tile
+    unsigned int wsum[SC_THREADS / 64 + 1];
+    uint32_t p;
+};
+constexpr int TILE1 = ScatterLds<1>::N, TILE2 = ScatterLds<2>::N;
+static_assert(TILE1 % SC_THREADS == 0 && TILE2 % SC_THREADS == 0, "whole entries per thread");
+static_assert(BINS1 % SC_THREADS == 0 && BINS2 % SC_THREADS == 0, "whole bins per thread");
+
+__global__ void __launch_bounds__(1024) tile_map_kernel(const uint64_t* off1, unsigned int* tile_off) {
+    __shared__ unsigned int v[BINS1];
+    for (int i = threadIdx.x; i < BINS1; i += 1024) v[i] = (unsigned int)((off1[i + 1] - off1[i] + TILE2 - 1) / TILE2);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int i = 0; i < BINS1; i++) {
+            unsigned int x = v[i];
+            v[i] = acc;
+            acc += x;
+        }
+        tile_off[BINS1] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS1; i += 1024) tile_off[i] = v[i];
+}
+
+// the level-2 tile of this workgroup: partition p and entry range [lo, hi); false = nothing to do
+__device__ __forceinline__ bool level2_tile(const uint64_t* off1, const unsigned int* tile_off, uint32_t* s_p, uint32_t& p, uint64_t& lo,
+                                            uint64_t& hi) {
+    const uint32_t n_tiles = tile_off[BINS1], per = (n_tiles + XCDS - 1) / XCDS;
+    if (blockIdx.x / XCDS >= per) return false;
+    const uint32_t tile = (blockIdx.x % XCDS) * per + blockIdx.x / XCDS;
+    if (tile >= n_tiles) return false;
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = BINS1;  // invariant: tile_off[a] <= tile < tile_off[b]
+        while (b - a > 1) {
+            uint32_t mid = (a + b) >> 1;
+            if (tile_off[mid] <= tile) a = mid;
+            else b = mid;
+        }
+        *s_p = a;
+    }
+    __syncthreads();
+    p = *s_p;
+    lo = off1[p] + (uint64_t)(tile - tile_off[p]) * TILE2;
+    const uint64_t pend = off1[p + 1];
+    hi = lo + TILE2 < pend ? lo + TILE2 : pend;
+    return true;
+}
+
+// leaf sizes: cnt2[partition * 2048 + d2]
+__global__ void __launch_bounds__(256) count2_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ off1,
+                                                     const unsigned int* __restrict__ tile_off, unsigned int* cnt2) {
+    __shared__ unsigned int l_cnt[BINS2];
+    __shared__ uint32_t s_p;
+    for (int i = threadIdx.x; i < BINS2; i += 256) l_cnt[i] = 0;
+    uint32_t p;
+    uint64_t lo, hi;
+    if (!level2_tile(off1, tile_off, &s_p, p, lo, hi)) return;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&l_cnt[d2_of(src[i])], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS2; i += 256)
+        if (l_cnt[i]) atomicAdd(&cnt2[(uint64_t)p * BINS2 + i], l_cnt[i]);
+}
+
+template <int LEVEL>
+__global__ void __launch_bounds__(SC_THREADS) scatter_kernel(const uint64_t* __restrict__ src, const uint16_t* __restrict__ d1,
+                                                             const unsigned long long* n_ent, uint64_t cap, const uint64_t* __restrict__ off1,
+                                                             const unsigned int* __restrict__ tile_off, uint64_t* __restrict__ dst,
+                                                             unsigned long long* cursor) {
+    __shared__ ScatterLds<LEVEL> L;
+    constexpr int N = ScatterLds<LEVEL>::N, BINS = ScatterLds<LEVEL>::BINS, EPT = N / SC_THREADS, BPT = BINS / SC_THREADS;
+    const uint32_t tid = threadIdx.x;
+    for (int i = tid; i < BINS; i += SC_THREADS) L.start[i] = 0;
+    uint64_t lo, hi;
+    if (LEVEL == 1) {
+        const uint64_t n = *n_ent < cap ? *n_ent : cap;
+        lo = (uint64_t)blockIdx.x * N;
+        if (lo >= n) return;
+        hi = lo + N < n ? lo + N : n;
+        __syncthreads();
+    } else {
+        uint32_t p;
+        if (!level2_tile(off1, tile_off, &L.p, p, lo, hi)) return;
+        cursor += (uint64_t)p * BINS;
+    }
+    // 1. load, rank inside the bin
+    uint64_t e[EPT];
+    uint16_t bin[EPT], rk[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const uint64_t i = lo + (uint64_t)k * SC_THREADS + tid;
+        e[k] = i < hi ? src[i] : ENT_INVALID;
+        if (LEVEL == 1) bin[k] = i < hi ? (uint16_t)(d1[i] & (BINS - 1)) : (uint16_t)0;
+        else bin[k] = (uint16_t)d2_of(e[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; k++) rk[k] = e[k] != ENT_INVALID ? (uint16_t)atomicAdd(&L.start[bin[k]], 1u) : (uint16_t)0;
+    __syncthreads();
+    // 2. exclusive scan of the counts (BPT consecutive bins per thread), one reservation per non-empty bin
+    unsigned int c[BPT], mine = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {
+        c[j] = L.start[BPT * tid + j];
+        mine += c[j];
+    }
+    unsigned int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned int y = (unsigned int)__shfl_up((int)incl, o, 64);
+        if ((tid & 63) >= (uint32_t)o) incl += y;
+    }
+    if ((tid & 63) == 63) L.wsum[tid >> 6] = incl;
+    __syncthreads();
+    unsigned int st = incl - mine;
+    for (uint32_t w = 0; w < (tid >> 6); w++) st += L.wsum[w];
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {  // (a thread's counts are read and replaced by itself only)
+        L.start[BPT * tid + j] = st;
+        if (c[j]) L.gbase[BPT * tid + j] = atomicAdd(&cursor[BPT * tid + j], (unsigned long long)c[j]) - st;
+        st += c[j];
+    }
+    if (tid == SC_THREADS - 1) L.wsum[SC_THREADS / 64] = st;  // entries of the tile
+    __syncthreads();
+    // 3. sorted order in LDS
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (e[k] != ENT_INVALID) {
+            const unsigned int at = L.start[bin[k]] + rk[k];
+            L.sorted[at] = e[k];
+            if (LEVEL == 1) L.sbin[at] = bin[k];
+        }
+    __syncthreads();
+    // 4. out, consecutive lanes = consecutive entries
+    const unsigned int total = L.wsum[SC_THREADS / 64];
+#pragma unroll 4
+    for (int k = 0; k < EPT; k++) {
+        const unsigned int i = (unsigned int)k * SC_THREADS + tid;
+        if (i >= total) break;
+        const uint64_t v = L.sorted[i];
+        const uint32_t b = LEVEL == 1 ? (uint32_t)L.sbin[i] : d2_of(v);
+        dst[L.gbase[b] + i] = v;
+    }
+}
+
+// Are the windows of W code points that start at text positions p and q identical?  (p is a window start, so its W code
+// points exist and are followed by at least one more byte of its document.)  Both windows are loaded 64 bytes at a
+// time (eight 16-byte loads in flight: one memory round trip covers a 50-character ASCII window); code-point
+// starts of p's bytes are counted on the way and the comparison stops at the byte where p's (W+1)-th code point starts.
+// (q is a window start too; while the bytes agree both windows have the same code-point structure, so no load goes
+// further than 70 bytes past the end of either window: inside MDD_TEXT_PAD.)
+constexpr int CMP_DW = 15;  // dwords compared per batch (60 bytes: a 50-character ASCII window in one batch)
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes at a 4-byte aligned address
+__device__ __forceinline__ bool same_window_cp(const uint8_t* text, uint64_t p, uint64_t q, uint32_t W) {
+    const uint32_t* tp = reinterpret_cast<const uint32_t*>(text) + (p >> 2);
+    const uint32_t* tq = reinterpret_cast<const uint32_t*>(text) + (q >> 2);
+    const uint32_t sp = (uint32_t)p & 3u, sq = (uint32_t)q & 3u;
+    uint32_t starts = 0;  // code-point starts of p seen so far
+    for (uint32_t off = 0;; off += CMP_DW) {
+        // every lane reads its own two places of the text, so what a load costs is the number of lane requests:
+        // four 16-byte loads per side instead of sixteen 4-byte ones
+        uint32_t ra[CMP_DW + 1], rb[CMP_DW + 1];
+#pragma unroll
+        for (int k = 0; k <= CMP_DW; k += 4) {
+            const u32x4_a4 va = *reinterpret_cast<const u32x4_a4*>(tp + off + k);
+            const u32x4_a4 vb = *reinterpret_cast<const u32x4_a4*>(tq + off + k);
+            ra[k] = va.x, ra[k + 1] = va.y, ra[k + 2] = va.z, ra[k + 3] = va.w;
+            rb[k] = vb.x, rb[k + 1] = vb.y, rb[k + 2] = vb.z, rb[k + 3] = vb.w;
+        }
+#pragma unroll
+        for (int k = 0; k < CMP_DW; k++) {
+            const uint32_t a = __builtin_amdgcn_alignbyte(ra[k + 1], ra[k], sp);
+            const uint32_t b = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sq);
+            // bit 0 of every byte of m: that byte is NOT a continuation byte (10xxxxxx)
+            const uint32_t m = ~((a >> 7) & ~(a >> 6)) & 0x01010101u;
+            const uint32_t n = __builtin_popcount(m);
+            const uint32_t x = a ^ b;
+            if (starts + n <= W) {  // the whole dword belongs to the window
+                if (x) return false;
+                starts += n;
+                continue;
+            }
+            // the window ends inside this dword: at the byte holding start number W+1 (counting from 1)
+            uint32_t need = W + 1 - starts, seen = 0, keep = 0;
+#pragma unroll
+            for (int by = 0; by < 4; by++) {
+                seen += (m >> (8 * by)) & 1u;
+                if (seen < need) keep |= 0xFFu << (8 * by);
+            }
+            return (x & keep) == 0;
+        }
+    }
+}
+
+struct LeafArgs {
+    const uint64_t* ent;
+    const uint64_t* off2;  // [2^22 + 1] leaf offsets
+    uint64_t n_leaves;
+    const uint8_t* text;
+    uint64_t text_bytes;
+    uint32_t window;
+    uint8_t* dup;
+    unsigned long long* overflow;
+    unsigned long long* prof;  // MDD_LEAF_PROF builds: cycles per phase, summed over waves
+};
+#ifdef MDD_LEAF_PROF
+#define LEAF_T(i)                                            \
+    {                                                        \
+        uint64_t t_now = __builtin_amdgcn_s_memtime();       \
+        t_acc[i] += t_now - t_last;                          \
+        t_last = t_now;                                      \
+    }
+#else
+#define LEAF_T(i)
+#endif
+
+// One WAVE per leaf (leaves are ~500 windows: a workgroup per leaf spends its time in barriers), leaves dealt out
+// statically (wave w takes leaves w, w + #waves, ...: a work counter would be 4 M same-address atomics = 46 ms).
+// The table entry is [d2 | tag : 28 | lowest position : 36] of one distinct window content; all-ones = empty.
+// A leaf costs memory round trips, not bandwidth, so the kernel is built to need few of them:
+//   * the leaf's entries are loaded LEAF_CH per lane in one go, and the NEXT leaf's entries are requested before
+//     this leaf is worked on;
+//   * inserting never touches the text: an entry that meets its tag in the table becomes a CANDIDATE (entry, slot) in an
+//     LDS list and leaves the slot unchanged;
+//   * candidates are resolved 64 at a time, every lane busy (a leaf of 500 windows has ~80): compare the bytes with the
+//     slot's window; equal -> the later window of the pair is marked and the slot keeps the lower position (atomicMin);
+//     different (a tag collision: the 17 tag bits that vary inside a leaf meet by chance about once per leaf) -> go on
+//     probing, verifying on the way.  A slot's CONTENT never changes once claimed, and every window of one content walks
+//     the same probe sequence, so deferring cannot split a group of equal windows over two slots.
+// wave_sync() without its fences, which make the compiler wait for the global loads in flight (the next leaf's entries)
+// as well.  Between the lanes of ONE wave the LDS needs no fence -- DS instructions of a wave execute in issue order --
+// only the compiler must keep its hands off the order: a compiler-level memory barrier on both sides of the wave barrier.
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+constexpr int LEAF_CH = 12;     // entries per lane and chunk: 768, above nearly every leaf's size
+constexpr int CAND_CAP = 256;   // candidate list entries (drained when 192 are queued)
+struct LeafLds {
+    unsigned long long tab[LEAF_SLOTS];
+    unsigned long long cval[CAND_CAP];
+    uint16_t cslot[CAND_CAP];
+};
+__device__ __forceinline__ uint32_t leaf_home(unsigned long long val) {
+    return ((uint32_t)(val >> POS_BITS) * 0x9E3779B1u) >> (32 - 10);
+}
+static_assert(LEAF_SLOTS == 1024, "leaf_home yields 10 bits");
+
+// the full protocol for one window, from `slot` on; true = it claimed an empty slot (a new distinct content)
+__device__ __forceinline__ bool leaf_resolve(LeafLds& L, const LeafArgs& A, unsigned long long val, uint32_t slot) {
+    const uint64_t pos = val & POS_M;
+    for (uint32_t probe = 0; probe < LEAF_SLOTS; probe++) {
+        unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
+        if (cur == ENT_INVALID) return true;
+        if ((cur >> POS_BITS) == (val >> POS_BITS) && same_window_cp(A.text, pos, cur & POS_M, A.window)) {
+            if (cur > val) cur = atomicMin(&L.tab[slot], val);
+            A.dup[cur > val ? (cur & POS_M) : pos] = 1;
+            return false;
+        }
+        slot = (slot + 1) & (LEAF_SLOTS - 1);
+    }
+    atomicAdd(A.overflow, 1ull);
+    return false;
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) leaf_kernel(LeafArgs A) {
+    __shared__ LeafLds L;
+    const uint32_t lane = lane_id();
+    const uint64_t n_waves = gridDim.x;
+    auto leaf_range = [&](uint64_t leaf, uint64_t& lo, uint64_t& hi) {
+        lo = hi = 0;
+        if (leaf < A.n_leaves) {
+            lo = A.off2[leaf];
+            hi = A.off2[leaf + 1];
+        }
+    };
+    auto load_chunk = [&](unsigned long long (&e)[LEAF_CH], uint64_t lo, uint64_t hi) {
+#pragma unroll
+        for (int k = 0; k < LEAF_CH; k++) {
+            const uint64_t i = lo + (uint64_t)k * 64 + lane;
+            e[k] = i < hi ? A.ent[i] : ENT_INVALID;
+        }
+    };
+    uint32_t n_cand = 0, distinct = 0;  // wave-uniform
+    auto drain = [&]() {
+        lds_sync();
+        for (uint32_t base = 0; base < n_cand; base += 64) {
+            bool claimed = false;
+            if (base + lane < n_cand) claimed = leaf_resolve(L, A, L.cval[base + lane], L.cslot[base + lane]);
+            distinct += (uint32_t)__popcll(__ballot(claimed));
+        }
+        lds_sync();
+        n_cand = 0;
+    };
+    // (a rolled loop over a rotating register array: unrolled, the body -- with the candidate drain inside -- came to
+    // 150 KB of code, more than the instruction cache holds)
+    auto insert_chunk = [&](unsigned long long (&e)[LEAF_CH]) {
+#pragma unroll 1
+        for (int k = 0; k < LEAF_CH; k++) {
+            const unsigned long long val = e[0];
+#pragma unroll
+            for (int j = 0; j + 1 < LEAF_CH; j++) e[j] = e[j + 1];
+            e[LEAF_CH - 1] = ENT_INVALID;
+            if (__ballot(val != ENT_INVALID) == 0) break;
+            bool claimed = false, cand = false;
+            uint32_t slot = leaf_home(val);
+            if (val != ENT_INVALID) {
+                for (uint32_t probe = 0; probe < LEAF_SLOTS; probe++) {
+                    const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
+                    if (cur == ENT_INVALID) {
+                        claimed = true;
+                        break;
+                    }
+                    if ((cur >> POS_BITS) == (val >> POS_BITS)) {
+                        cand = true;
+                        break;
+                    }
+                    slot = (slot + 1) & (LEAF_SLOTS - 1);
+                }
+                if (!claimed && !cand) atomicAdd(A.overflow, 1ull);  // table full
+            }
+            distinct += (uint32_t)__popcll(__ballot(claimed));
+            const uint64_t cb = __ballot(cand);
+            if (cand) {
+                const uint32_t at = n_cand + below(cb);
+                L.cval[at] = val;
+                L.cslot[at] = (uint16_t)slot;
+            }
+            n_cand += (uint32_t)__popcll(cb);
+            if (n_cand > CAND_CAP - 64) drain();
+        }
+    };
+
+#ifdef MDD_LEAF_PROF
+    uint64_t t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+#endif
+    uint64_t leaf = blockIdx.x;
+    uint64_t lo, hi, nlo, nhi;
+    leaf_range(leaf, lo, hi);
+    leaf_range(leaf + n_waves, nlo, nhi);
+    unsigned long long e[LEAF_CH], nx[LEAF_CH];
+    load_chunk(e, lo, hi);
+    while (leaf < A.n_leaves) {
+        // requests for the following leaf (entries) and the one after it (range) go out before this leaf's work
+        load_chunk(nx, nlo, nhi);
+        uint64_t nnlo, nnhi;
+        leaf_range(leaf + 2 * n_waves, nnlo, nnhi);
+        LEAF_T(0)
+        if (hi - lo >= 2) {  // a leaf with one window has no repeats
+#pragma unroll
+            for (int i = 0; i < LEAF_SLOTS / 64; i++) L.tab[i * 64 + lane] = ENT_INVALID;
+            lds_sync();
+            LEAF_T(1)
+            distinct = 0;
+            insert_chunk(e);  // requested a leaf ago; kept apart from the loop below so that the wait for e does not cover nx
+            for (uint64_t c0 = lo + 64 * LEAF_CH; c0 < hi && distinct <= LEAF_SLOTS * 3 / 4; c0 += 64 * LEAF_CH) {  // the rare long leaf
+                unsigned long long more[LEAF_CH];
+                load_chunk(more, c0, hi);
+                insert_chunk(more);
+            }
+            LEAF_T(2)
+            drain();
+            LEAF_T(3)
+            // the table is filling up: chains get long and then it is full -- refuse (mdd_substr_check)
+            if (distinct > LEAF_SLOTS * 3 / 4 && lane == 0) atomicAdd(A.overflow, 1ull);
+        }
+#pragma unroll
+        for (int k = 0; k < LEAF_CH; k++) e[k] = nx[k];
+        lo = nlo, hi = nhi, nlo = nnlo, nhi = nnhi;
+        leaf += n_waves;
+        LEAF_T(4)
+    }
+#ifdef MDD_LEAF_PROF
+    if (lane == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(&A.prof[i], (unsigned long long)t_acc[i]);
+#endif
+}
+
+}  // namespace
+
+extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                                      int window, int part, int n_parts, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap,
+                                      uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup) {
+    REQUIRE(ctx, "mdd_substr_mark_sorted: ctx is NULL");
+    REQUIRE(window >= 1 && window <= 128, "mdd_substr_mark_sorted: window=%d outside [1,128]", window);
+    REQUIRE(text_bytes < (1ULL << POS_BITS), "mdd_substr_mark_sorted: text_bytes must be below 2^36 (use mdd_substr_mark beyond)");
+    REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "mdd_substr_mark_sorted: part=%d outside [0,%d)", part, n_parts);
+    if (n_docs == 0 || text_bytes == 0) return MDD_OK;
+    REQUIRE(text && offsets && ent_a && ent_b && d1_ws && ws && dup, "mdd_substr_mark_sorted: NULL buffer");
+    REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_mark_sorted: text must be 4-byte aligned");
+    const uint64_t n_leaves = (uint64_t)BINS1 * BINS2;
+    // workspace layout (u64 words): off1[BINS1+1] | cursor1[BINS1] | off2[n_leaves+1] | cursor2[n_leaves] | hist1 (u32 x BINS1) |
+    // cnt2 (u32 x n_leaves) | counters[8] | scan scratch[1024] | tile_off (u32 x (BINS1+2))
+    const uint64_t need_words = (BINS1 + 1) + BINS1 + (n_leaves + 1) + n_leaves + BINS1 / 2 + n_leaves / 2 + 8 + 1024 + (BINS1 + 2) / 2;
+    static_assert((BINS1 + 1) + BINS1 + ((uint64_t)BINS1 * BINS2 + 1) + (uint64_t)BINS1 * BINS2 + BINS1 / 2 + (uint64_t)BINS1 * BINS2 / 2 + 8 + 1024 +
+                          (BINS1 + 2) / 2 ==
+                      MDD_SUBSTR_SORTED_WS_WORDS,
+                  "include/mdd.h: MDD_SUBSTR_SORTED_WS_WORDS");
+    REQUIRE(ws_words >= need_words, "mdd_substr_mark_sorted: workspace of %llu u64 words needed (MDD_SUBSTR_SORTED_WS_WORDS)",
+            (unsigned long long)need_words);
+    REQUIRE((reinterpret_cast<uintptr_t>(ent_a) & 7u) == 0 && (reinterpret_cast<uintptr_t>(ent_b) & 7u) == 0 &&
+                (reinterpret_cast<uintptr_t>(d1_ws) & 1u) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0,
+            "mdd_substr_mark_sorted: ent_a, ent_b, ws must be 8-byte aligned, d1_ws 2-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t waves = (uint64_t)ctx->cus * 4 * 7;
+    REQUIRE(ent_cap >= waves * EMIT_CHUNK + TILE1 && ent_cap < (1ULL << 40),
+            "mdd_substr_mark_sorted: ent_cap=%llu too small (need the windows of the pass + %llu)", (unsigned long long)ent_cap,
+            (unsigned long long)(waves * EMIT_CHUNK + TILE1));
+    uint64_t* off1 = ws;
+    unsigned long long* cursor1 = reinterpret_cast<unsigned long long*>(off1 + BINS1 + 1);
+    uint64_t* off2 = reinterpret_cast<uint64_t*>(cursor1 + BINS1);
+    unsigned long long* cursor2 = reinterpret_cast<unsigned long long*>(off2 + n_leaves + 1);
+    unsigned int* hist1 = reinterpret_cast<unsigned int*>(cursor2 + n_leaves);
+    unsigned int* cnt2 = hist1 + BINS1;
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(cnt2 + n_leaves);  // [0] entries handed out
+    uint64_t* sums = reinterpret_cast<uint64_t*>(counters + 8);                              // scratch of the scans (1024 words)
+    unsigned int* tile_off = reinterpret_cast<unsigned int*>(sums + 1024);                   // [BINS1 + 1]
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemsetAsync(hist1, 0, (BINS1 + n_leaves) * sizeof(unsigned int) + 8 * sizeof(uint64_t), st));
+    if (part == 0) HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));
+    // ---- emit
+    EmitArgs E{};
+    E.text = text;
+    E.text_bytes = text_bytes;
+    E.offsets = offsets;
+    E.n_docs = n_docs;
+    E.window = (uint32_t)window;
+    uint64_t seg = ctx->seg_bytes, need = text_bytes / SEG_ITEM_CAP + 1;
+    if (seg < need) seg = need;
+    seg = (seg + 255) / 256 * 256;
+    REQUIRE(seg <= 0xFFFFFF00ull, "mdd_substr_mark_sorted: text too large for the segment plan");
+    uint64_t max_items = text_bytes / seg;
+    if (max_items > SEG_ITEM_CAP) max_items = SEG_ITEM_CAP;
+    E.seg_bytes = (uint32_t)seg;
+    E.items = ctx->seg_items;
+    E.n_items = ctx->seg_n_items;
+    E.max_items = max_items;
+    E.work_counter = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 1);
+    E.ent = ent_a;
+    E.ent_cap = ent_cap;
+    E.n_ent = counters;
+    E.hist1 = hist1;
+    E.overflow = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 2);
+    E.part = (uint32_t)part;
+    E.n_parts = (uint32_t)n_parts;
+    E.d1 = d1_ws;
+    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, st, offsets, n_docs, text_bytes, E.seg_bytes,
+                       ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, (uint32_t*)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((w + EMIT_WAVES - 1) / EMIT_WAVES)), dim3(64 * EMIT_WAVES), 0, st, E);
+    HIP_TRY(hipGetLastError());
+    // ---- level 1
+    {
+        int rc = exclusive_scan(st, hist1, (uint64_t)BINS1, off1, sums);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(cursor1, off1, BINS1 * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(scatter_kernel<1>, dim3((unsigned)((ent_cap + TILE1 - 1) / TILE1)), dim3(SC_THREADS), 0, st, ent_a, d1_ws, counters, ent_cap,
+                       off1, tile_off, ent_b, cursor1);
+    HIP_TRY(hipGetLastError());
+    // ---- level 2
+    const unsigned max_tiles2 = (unsigned)((ent_cap / TILE2 + BINS1 + XCDS - 1) / XCDS * XCDS);
+    hipLaunchKernelGGL(tile_map_kernel, dim3(1), dim3(1024), 0, st, off1, tile_off);
+    hipLaunchKernelGGL(count2_kernel, dim3(max_tiles2), dim3(256), 0, st, ent_b, off1, tile_off, cnt2);
+    {
+        int rc = exclusive_scan(st, cnt2, n_leaves, off2, sums);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(cursor2, off2, n_leaves * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(scatter_kernel<2>, dim3(max_tiles2), dim3(SC_THREADS), 0, st, ent_b, (const uint16_t*)nullptr, counters, ent_cap, off1,
+                       tile_off, ent_a, cursor2);
+    HIP_TRY(hipGetLastError());
+    // ---- leaves
+    LeafArgs L{};
+    L.ent = ent_a;
+    L.off2 = off2;
+    L.n_leaves = n_leaves;
+    L.text = text;
+    L.text_bytes = text_bytes;
+    L.window = (uint32_t)window;
+    L.dup = dup;
+    L.overflow = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 2);
+    L.prof = counters + 1;
+    hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)ctx->cus * 14), dim3(64), 0, st, L);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}

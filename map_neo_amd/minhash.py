@@ -92,6 +92,8 @@ class Engine:
         self._perm_cache = {}
         # bucket table slots per band record (rounded up to a power of two): load factor <= 1 / table_factor
         self.table_factor = float(os.environ.get("MDD_TABLE_FACTOR", "2.0"))
+        # exact substring dedup: "table" (mdd_substr_mark), "sorted" (mdd_substr_mark_sorted) or "auto" (by size)
+        self.substr_method = os.environ.get("MDD_SUBSTR_METHOD", "auto")
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -388,8 +390,10 @@ class Engine:
         out_offs = torch.cat([out_offs_all[:-1][docs], out_offs_all[-1:]])
         return out_text, out_offs, docs
 
+    SUBSTR_WS_WORDS = 10492939      # MDD_SUBSTR_SORTED_WS_WORDS
+
     def substr_dedup(self, text: torch.Tensor, offsets: torch.Tensor, window: int = 50, min_length: int = 20,
-                     table_bytes: Optional[int] = None):
+                     table_bytes: Optional[int] = None, method: str = "auto"):
         """Exact substring dedup of a packed corpus (SUB:34-95).  Returns (out_text uint8 [padded],
         out_offsets int64 [n_kept+1], kept document indices int64).  The window table (16 bytes per window)
         is limited to table_bytes (default: 40 % of the free HBM); beyond that the windows are processed in
@@ -404,13 +408,38 @@ class Engine:
         dup = self.empty(max(1, text_bytes), torch.uint8)
         if table_bytes is None:
             table_bytes = int(torch.cuda.mem_get_info(self.device)[0] * 0.4)
-        n_parts = max(1, -(-(16 * n_win) // max(1, table_bytes)))
-        slots = 2 * n_win if n_parts == 1 else int(2.2 * n_win / n_parts) + 4096      # hash partitions are only nearly equal
-        table = self.empty(max(2, slots), torch.int64)
-        for part in range(n_parts):
-            _lib.check(self.L.mdd_substr_mark(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
-                                              _ptr(table), table.numel(), _ptr(dup)), "mdd_substr_mark")
+        # "sorted": partition the windows into leaves and group them in LDS (mdd_substr_mark_sorted) -- pays once the
+        # table of the "table" method (one random atomic per window) is far beyond the caches; "table": mdd_substr_mark
+        if method == "auto":
+            method = self.substr_method
+        if method == "auto":
+            method = "sorted" if (n_win >= (1 << 24) and text_bytes < (1 << 36)) else "table"
+        if method == "sorted":
+            slack = 2048 * 28 * torch.cuda.get_device_properties(self.device).multi_processor_count + 14336
+            per_win = 2 * 8 + 2                                                  # two entry arrays + the u16 side array
+            n_parts = max(1, -(-int(1.06 * n_win * per_win + slack * per_win) // max(1, table_bytes)))
+            cap = int(1.06 * n_win / n_parts) + slack + (n_win // n_parts // 16 if n_parts > 1 else 0)   # key partitions are only nearly equal
+            ent_a, ent_b = self.empty(cap, torch.int64), self.empty(cap, torch.int64)
+            d1 = self.empty(cap, torch.int16)
+            ws = self.empty(self.SUBSTR_WS_WORDS, torch.int64)
+            for part in range(n_parts):
+                _lib.check(self.L.mdd_substr_mark_sorted(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
+                                                         _ptr(ent_a), _ptr(ent_b), cap, _ptr(d1), _ptr(ws), ws.numel(), _ptr(dup)),
+                           "mdd_substr_mark_sorted")
+            table = (ent_a, ent_b, d1, ws)
+            if os.environ.get("MDD_LEAF_PROF"):      # profiling builds (-DMDD_LEAF_PROF): cycles per leaf-kernel phase
+                torch.cuda.synchronize(self.device)
+                base = (2048 + 1) + 2048 + (2 ** 22 + 1) + 2 ** 22 + 1024 + 2 ** 21
+                self.last_leaf_prof = ws[base + 1: base + 6].tolist()
+        else:
+            n_parts = max(1, -(-(16 * n_win) // max(1, table_bytes)))
+            slots = 2 * n_win if n_parts == 1 else int(2.2 * n_win / n_parts) + 4096      # hash partitions are only nearly equal
+            table = self.empty(max(2, slots), torch.int64)
+            for part in range(n_parts):
+                _lib.check(self.L.mdd_substr_mark(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
+                                                  _ptr(table), table.numel(), _ptr(dup)), "mdd_substr_mark")
         self.last_substr_parts = n_parts
+        self.last_substr_method = method
         del table
         _lib.check(self.L.mdd_substr_check(self.ctx, None), "mdd_substr_mark")      # an undersized table is an error, not a miss
         kept_b = torch.zeros(n, dtype=torch.int64, device=self.device)

@@ -180,10 +180,10 @@ def test_substr_partitioned_passes_equal_single_pass_at_scale(engine):
     from map_neo_amd import corpus
     spec = corpus.CorpusSpec(200_000, 2048, lang="en", seed=5)
     text, offs = corpus.generate_chunked(spec, engine.device)
-    a = engine.substr_dedup(text, offs, 50, 20)
+    a = engine.substr_dedup(text, offs, 50, 20, method="table")
     assert engine.last_substr_parts == 1
     n_win = int(torch.clamp(offs[1:] - offs[:-1] - 50, min=0).sum().item())
-    b = engine.substr_dedup(text, offs, 50, 20, table_bytes=16 * n_win // 7 + 1)
+    b = engine.substr_dedup(text, offs, 50, 20, table_bytes=16 * n_win // 7 + 1, method="table")
     assert engine.last_substr_parts == 7
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     n = int(a[1][-1].item())
@@ -241,3 +241,54 @@ def test_substr_undersized_table_is_an_error_not_a_miss(engine):
     assert engine.L.mdd_substr_check(engine.ctx, C.byref(n_over)) == 0 and n_over.value == 0       # the count was cleared
     rows = [(d, i) for i, d in enumerate(docs + docs[:5])]
     assert exact.exact_substr_dedup(engine, rows, 50, 20) == RX.exact_substr_dedup(rows, 50, 20)
+
+
+@pytest.fixture()
+def sorted_method(engine):
+    engine.substr_method = "sorted"
+    yield engine
+    engine.substr_method = "auto"
+
+
+def test_substr_sorted_method_vs_oracle(sorted_method):
+    """mdd_substr_mark_sorted (windows partitioned into leaves, grouped in LDS) == the oracle: random utf-8 documents built
+    from shared pieces, windows 1 / 13 / 50 / 128, tiny segments, exact copies, ASCII + CJK + emoji"""
+    engine = sorted_method
+    rng = np.random.Generator(np.random.PCG64(77))
+    for rep in range(6):
+        docs = _corpus(rng, 60)
+        docs += ["".join(chr(int(c)) for c in rng.integers(0x4E00, 0x4E40, 300)) for _ in range(5)]
+        docs += [docs[-1], docs[-2][:120] + "尾", "😀" * 80, "😀" * 81]
+        window = [50, 13, 1, 128, 50, 2][rep]
+        seg = [0, 256, 0, 1024, 512, 0][rep]
+        engine.set_segment_bytes(seg)
+        try:
+            rows = [(d, i) for i, d in enumerate(docs)]
+            assert exact.exact_substr_dedup(engine, rows, window, 20) == RX.exact_substr_dedup(rows, window, 20), (window, seg)
+            assert engine.last_substr_method == "sorted"
+        finally:
+            engine.set_segment_bytes(0)
+
+
+def test_substr_sorted_method_heavy_repetition_and_parts(sorted_method):
+    """one leaf with hundreds of thousands of identical windows (boilerplate), several key-partitioned passes, and the
+    same survivors as the table method on 100 k synthetic documents"""
+    import torch
+    from map_neo_amd import corpus
+    engine = sorted_method
+    boiler = "this site uses cookies to improve your experience please accept our terms " * 3
+    rng = np.random.Generator(np.random.PCG64(5))
+    docs = [boiler + " ".join("w%d" % int(x) for x in rng.integers(0, 50, 12)) + boiler for _ in range(300)]
+    rows = [(d, i) for i, d in enumerate(docs)]
+    assert exact.exact_substr_dedup(engine, rows, 50, 20) == RX.exact_substr_dedup(rows, 50, 20)
+    spec = corpus.CorpusSpec(100_000, 2048, lang="mixed", seed=5, boiler_frac=0.05, n_templates=20)
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    a = engine.substr_dedup(text, offs, 50, 20, method="sorted")
+    assert engine.last_substr_parts == 1 and engine.last_substr_method == "sorted"
+    b = engine.substr_dedup(text, offs, 50, 20, method="table")
+    n = int(a[1][-1].item())
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0][:n], b[0][:n]) and 0 < n < int(offs[-1].item())
+    n_win = int(torch.clamp(offs[1:] - offs[:-1] - 50, min=0).sum().item())
+    c = engine.substr_dedup(text, offs, 50, 20, method="sorted", table_bytes=int(18 * 1.06 * n_win / 3))
+    assert engine.last_substr_parts >= 3
+    assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]) and torch.equal(a[0][:n], c[0][:n])
