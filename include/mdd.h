@@ -302,16 +302,19 @@ int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
 int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                     int window, int part, int n_parts, uint64_t* table, uint64_t tab_size, uint8_t* dup);
 /*   mark_sorted: the same marks as `mark`, computed without random atomics on a big table (mdd_substr_part.hip): every
- *          window becomes an 8-byte entry, two 2048-way partition passes (streaming traffic only) sort the entries into
- *          2^22 leaves by content key, and one workgroup per leaf groups its ~500 windows in an LDS table (tag matches
- *          confirmed on the bytes, so the result is exact).  About twice as fast as `mark` on corpora of millions of
- *          documents.  text_bytes < 2^36.  Workspaces (caller-allocated, contents irrelevant):
+ *          window becomes an 8-byte entry, two 2048-way partition passes (tiles sorted by bin in LDS, so the stores are
+ *          runs, not single entries) sort the entries into 2^22 leaves by content key, and one wave per leaf groups its
+ *          ~500 windows in an LDS table (tag matches confirmed on the bytes, so the result is exact).  Leaves above
+ *          16384 windows (boilerplate, separator lines) are sliced over all waves and joined through a small global
+ *          table.  About twice as fast as `mark` on corpora of millions of documents (C2: 75 ms against 154 ms).
+ *          text_bytes < 2^36.  Workspaces (caller-allocated, contents irrelevant):
  *            ent_a, ent_b  u64[ent_cap] each, ent_cap >= 1.05 x windows of the pass + 2048 x 28 x CUs + 12288
  *            d1_ws         u16[ent_cap]
- *            ws            u64[ws_words], ws_words >= MDD_SUBSTR_SORTED_WS_WORDS
+ *            ws            u64[ws_words], ws_words >= MDD_SUBSTR_SORTED_WS_WORDS (89 MiB)
  *          part / n_parts as for `mark` (windows are split by content key; part 0 clears dup).  An entry array that is
- *          too small, or more than 768 distinct windows in one leaf, is counted and reported by mdd_substr_check. */
-#define MDD_SUBSTR_SORTED_WS_WORDS 10492939ull
+ *          too small, or more than 768 distinct windows in one leaf (or one 4096-window slice of a big leaf), is
+ *          counted and reported by mdd_substr_check: redo with more parts, or use `mark`. */
+#define MDD_SUBSTR_SORTED_WS_WORDS 11672587ull
 int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                            int window, int part, int n_parts, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap,
                            uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup);

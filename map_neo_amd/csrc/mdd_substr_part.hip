@@ -469,7 +469,14 @@ struct LeafArgs {
     uint8_t* dup;
     unsigned long long* overflow;
     unsigned long long* prof;  // MDD_LEAF_PROF builds: cycles per phase, summed over waves
+    unsigned int* n_big;       // leaves queued for bigleaf_kernel
+    unsigned int* big_list;    // [BIG_LIST_CAP]
+    unsigned long long* big_tab;  // [2^BIG_TAB_BITS], all-ones = empty
 };
+constexpr uint32_t BIG_LEAF = 16384;      // a leaf above this many windows is sliced over all waves
+constexpr uint32_t BIG_SLICE = 4096;
+constexpr uint32_t BIG_LIST_CAP = 1u << 18;
+constexpr int BIG_TAB_BITS = 20;
 #ifdef MDD_LEAF_PROF
 #define LEAF_T(i)                                            \
     {                                                        \
@@ -531,26 +538,28 @@ __device__ __forceinline__ bool leaf_resolve(LeafLds& L, const LeafArgs& A, unsi
     return false;
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) leaf_kernel(LeafArgs A) {
-    __shared__ LeafLds L;
-    const uint32_t lane = lane_id();
-    const uint64_t n_waves = gridDim.x;
-    auto leaf_range = [&](uint64_t leaf, uint64_t& lo, uint64_t& hi) {
-        lo = hi = 0;
-        if (leaf < A.n_leaves) {
-            lo = A.off2[leaf];
-            hi = A.off2[leaf + 1];
-        }
-    };
-    auto load_chunk = [&](unsigned long long (&e)[LEAF_CH], uint64_t lo, uint64_t hi) {
+// one wave's state while it works on a leaf (or on a slice of a big leaf)
+struct LeafWave {
+    LeafLds& L;
+    const LeafArgs& A;
+    const uint32_t lane;
+    uint32_t n_cand = 0, distinct = 0;  // wave-uniform
+    __device__ __forceinline__ LeafWave(LeafLds& l, const LeafArgs& a, uint32_t ln) : L(l), A(a), lane(ln) {}
+
+    __device__ __forceinline__ void load_chunk(unsigned long long (&e)[LEAF_CH], uint64_t lo, uint64_t hi) const {
 #pragma unroll
         for (int k = 0; k < LEAF_CH; k++) {
             const uint64_t i = lo + (uint64_t)k * 64 + lane;
             e[k] = i < hi ? A.ent[i] : ENT_INVALID;
         }
-    };
-    uint32_t n_cand = 0, distinct = 0;  // wave-uniform
-    auto drain = [&]() {
+    }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < LEAF_SLOTS / 64; i++) L.tab[i * 64 + lane] = ENT_INVALID;
+        lds_sync();
+        distinct = 0;
+    }
+    __device__ __forceinline__ void drain() {
         lds_sync();
         for (uint32_t base = 0; base < n_cand; base += 64) {
             bool claimed = false;
@@ -559,10 +568,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
         lds_sync();
         n_cand = 0;
-    };
+    }
     // (a rolled loop over a rotating register array: unrolled, the body -- with the candidate drain inside -- came to
     // 150 KB of code, more than the instruction cache holds)
-    auto insert_chunk = [&](unsigned long long (&e)[LEAF_CH]) {
+    __device__ __forceinline__ void insert_chunk(unsigned long long (&e)[LEAF_CH]) {
 #pragma unroll 1
         for (int k = 0; k < LEAF_CH; k++) {
             const unsigned long long val = e[0];
@@ -597,8 +606,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             n_cand += (uint32_t)__popcll(cb);
             if (n_cand > CAND_CAP - 64) drain();
         }
-    };
+    }
+    // entries [lo, hi) into the (cleared) table; `first` holds the first chunk already
+    __device__ __forceinline__ void run(uint64_t lo, uint64_t hi, unsigned long long (&first)[LEAF_CH]) {
+        insert_chunk(first);  // kept apart from the loop below so that the wait for `first` does not cover later requests
+        for (uint64_t c0 = lo + 64 * LEAF_CH; c0 < hi && distinct <= LEAF_SLOTS * 3 / 4; c0 += 64 * LEAF_CH) {
+            unsigned long long more[LEAF_CH];
+            load_chunk(more, c0, hi);
+            insert_chunk(more);
+        }
+        drain();
+        // the table is filling up: chains get long and then it is full -- refuse (mdd_substr_check)
+        if (distinct > LEAF_SLOTS * 3 / 4 && lane == 0) atomicAdd(A.overflow, 1ull);
+    }
+};
 
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) leaf_kernel(LeafArgs A) {
+    __shared__ LeafLds L;
+    const uint32_t lane = lane_id();
+    const uint64_t n_waves = gridDim.x;
+    LeafWave W(L, A, lane);
+    auto leaf_range = [&](uint64_t leaf, uint64_t& lo, uint64_t& hi) {
+        lo = hi = 0;
+        if (leaf < A.n_leaves) {
+            lo = A.off2[leaf];
+            hi = A.off2[leaf + 1];
+        }
+    };
 #ifdef MDD_LEAF_PROF
     uint64_t t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -607,30 +641,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     leaf_range(leaf, lo, hi);
     leaf_range(leaf + n_waves, nlo, nhi);
     unsigned long long e[LEAF_CH], nx[LEAF_CH];
-    load_chunk(e, lo, hi);
+    W.load_chunk(e, lo, hi);
     while (leaf < A.n_leaves) {
         // requests for the following leaf (entries) and the one after it (range) go out before this leaf's work
-        load_chunk(nx, nlo, nhi);
+        W.load_chunk(nx, nlo, nhi);
         uint64_t nnlo, nnhi;
         leaf_range(leaf + 2 * n_waves, nnlo, nnhi);
         LEAF_T(0)
-        if (hi - lo >= 2) {  // a leaf with one window has no repeats
-#pragma unroll
-            for (int i = 0; i < LEAF_SLOTS / 64; i++) L.tab[i * 64 + lane] = ENT_INVALID;
-            lds_sync();
-            LEAF_T(1)
-            distinct = 0;
-            insert_chunk(e);  // requested a leaf ago; kept apart from the loop below so that the wait for e does not cover nx
-            for (uint64_t c0 = lo + 64 * LEAF_CH; c0 < hi && distinct <= LEAF_SLOTS * 3 / 4; c0 += 64 * LEAF_CH) {  // the rare long leaf
-                unsigned long long more[LEAF_CH];
-                load_chunk(more, c0, hi);
-                insert_chunk(more);
+        if (hi - lo > BIG_LEAF) {
+            // boilerplate / runs of one character: one wave would be busy for milliseconds.  Queue it for bigleaf_kernel.
+            if (lane == 0) {
+                const unsigned int at = atomicAdd(A.n_big, 1u);
+                if (at < BIG_LIST_CAP) A.big_list[at] = (unsigned int)leaf;
+                else atomicAdd(A.overflow, 1ull);  // (cannot happen below 2^32 entries: 2^32 / BIG_LEAF < BIG_LIST_CAP)
             }
-            LEAF_T(2)
-            drain();
+        } else if (hi - lo >= 2) {  // a leaf with one window has no repeats
+            W.clear();
+            LEAF_T(1)
+            W.run(lo, hi, e);
             LEAF_T(3)
-            // the table is filling up: chains get long and then it is full -- refuse (mdd_substr_check)
-            if (distinct > LEAF_SLOTS * 3 / 4 && lane == 0) atomicAdd(A.overflow, 1ull);
         }
 #pragma unroll
         for (int k = 0; k < LEAF_CH; k++) e[k] = nx[k];
@@ -642,6 +671,54 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (lane == 0)
         for (int i = 0; i < 5; i++) atomicAdd(&A.prof[i], (unsigned long long)t_acc[i]);
 #endif
+}
+
+// The same protocol as leaf_resolve on the global table that joins the slices of big leaves.  Different leaves share
+// the table; a slot of another leaf (or another content) simply fails the byte comparison and the probe goes on.
+__device__ __forceinline__ void big_resolve(const LeafArgs& A, unsigned long long val, uint32_t leaf) {
+    const uint64_t pos = val & POS_M;
+    uint32_t slot = (((uint32_t)(val >> POS_BITS) ^ (leaf * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - BIG_TAB_BITS);
+    for (uint32_t probe = 0; probe < (1u << BIG_TAB_BITS); probe++) {
+        unsigned long long cur = atomicCAS(&A.big_tab[slot], ENT_INVALID, val);
+        if (cur == ENT_INVALID) return;
+        if ((cur >> POS_BITS) == (val >> POS_BITS) && same_window_cp(A.text, pos, cur & POS_M, A.window)) {
+            if (cur > val) cur = atomicMin(&A.big_tab[slot], val);
+            A.dup[cur > val ? (cur & POS_M) : pos] = 1;
+            return;
+        }
+        slot = (slot + 1) & ((1u << BIG_TAB_BITS) - 1);
+    }
+    atomicAdd(A.overflow, 1ull);
+}
+
+// Big leaves, all waves on each of them: a wave takes slices of BIG_SLICE entries, groups a slice in its LDS table exactly
+// as leaf_kernel groups a leaf (every window but the slice's first of each content is marked), then enters the slice's
+// survivors -- one per distinct content, what is left in the LDS table -- into a global table, which marks all but
+// the first across slices.  Every wave reads the same list and runs the same loops, so all of them reach the end.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) bigleaf_kernel(LeafArgs A) {
+    __shared__ LeafLds L;
+    const uint32_t lane = lane_id();
+    LeafWave W(L, A, lane);
+    unsigned int n_big = *A.n_big;
+    if (n_big > BIG_LIST_CAP) n_big = BIG_LIST_CAP;
+    for (unsigned int b = 0; b < n_big; b++) {
+        const uint32_t leaf = A.big_list[b];
+        if (leaf >= A.n_leaves) continue;
+        const uint64_t lo = A.off2[leaf], hi = A.off2[leaf + 1];
+        const uint64_t n_slices = (hi - lo + BIG_SLICE - 1) / BIG_SLICE;
+        for (uint64_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
+            const uint64_t slo = lo + sl * BIG_SLICE, shi = slo + BIG_SLICE < hi ? slo + BIG_SLICE : hi;
+            W.clear();
+            unsigned long long e[LEAF_CH];
+            W.load_chunk(e, slo, shi);
+            W.run(slo, shi, e);
+            for (int i = 0; i < LEAF_SLOTS / 64; i++) {
+                const unsigned long long v = L.tab[i * 64 + lane];
+                if (v != ENT_INVALID) big_resolve(A, v, leaf);
+            }
+            lds_sync();
+        }
+    }
 }
 
 }  // namespace
@@ -658,12 +735,12 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_mark_sorted: text must be 4-byte aligned");
     const uint64_t n_leaves = (uint64_t)BINS1 * BINS2;
     // workspace layout (u64 words): off1[BINS1+1] | cursor1[BINS1] | off2[n_leaves+1] | cursor2[n_leaves] | hist1 (u32 x BINS1) |
-    // cnt2 (u32 x n_leaves) | counters[8] | scan scratch[1024] | tile_off (u32 x (BINS1+2))
-    const uint64_t need_words = (BINS1 + 1) + BINS1 + (n_leaves + 1) + n_leaves + BINS1 / 2 + n_leaves / 2 + 8 + 1024 + (BINS1 + 2) / 2;
-    static_assert((BINS1 + 1) + BINS1 + ((uint64_t)BINS1 * BINS2 + 1) + (uint64_t)BINS1 * BINS2 + BINS1 / 2 + (uint64_t)BINS1 * BINS2 / 2 + 8 + 1024 +
-                          (BINS1 + 2) / 2 ==
-                      MDD_SUBSTR_SORTED_WS_WORDS,
-                  "include/mdd.h: MDD_SUBSTR_SORTED_WS_WORDS");
+    // cnt2 (u32 x n_leaves) | counters[8] | scan scratch[1024] | tile_off (u32 x (BINS1+2)) | big_list (u32 x BIG_LIST_CAP) |
+    // big_tab[2^BIG_TAB_BITS]
+    constexpr uint64_t NL = (uint64_t)BINS1 * BINS2;
+    constexpr uint64_t need_words =
+        (BINS1 + 1) + BINS1 + (NL + 1) + NL + BINS1 / 2 + NL / 2 + 8 + 1024 + (BINS1 + 2) / 2 + BIG_LIST_CAP / 2 + (1ull << BIG_TAB_BITS);
+    static_assert(need_words == MDD_SUBSTR_SORTED_WS_WORDS, "include/mdd.h: MDD_SUBSTR_SORTED_WS_WORDS");
     REQUIRE(ws_words >= need_words, "mdd_substr_mark_sorted: workspace of %llu u64 words needed (MDD_SUBSTR_SORTED_WS_WORDS)",
             (unsigned long long)need_words);
     REQUIRE((reinterpret_cast<uintptr_t>(ent_a) & 7u) == 0 && (reinterpret_cast<uintptr_t>(ent_b) & 7u) == 0 &&
@@ -683,6 +760,8 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     unsigned long long* counters = reinterpret_cast<unsigned long long*>(cnt2 + n_leaves);  // [0] entries handed out
     uint64_t* sums = reinterpret_cast<uint64_t*>(counters + 8);                              // scratch of the scans (1024 words)
     unsigned int* tile_off = reinterpret_cast<unsigned int*>(sums + 1024);                   // [BINS1 + 1]
+    unsigned int* big_list = tile_off + BINS1 + 2;
+    unsigned long long* big_tab = reinterpret_cast<unsigned long long*>(big_list + BIG_LIST_CAP);
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemsetAsync(hist1, 0, (BINS1 + n_leaves) * sizeof(unsigned int) + 8 * sizeof(uint64_t), st));
     if (part == 0) HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));
@@ -751,7 +830,12 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     L.dup = dup;
     L.overflow = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 2);
     L.prof = counters + 1;
+    L.n_big = reinterpret_cast<unsigned int*>(counters + 6);  // zeroed with the counters above
+    L.big_list = big_list;
+    L.big_tab = big_tab;
+    HIP_TRY(hipMemsetAsync(big_tab, 0xFF, sizeof(uint64_t) << BIG_TAB_BITS, st));
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)ctx->cus * 14), dim3(64), 0, st, L);
+    hipLaunchKernelGGL(bigleaf_kernel, dim3((unsigned)ctx->cus * 14), dim3(64), 0, st, L);  // returns at once when nothing was queued
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

@@ -390,7 +390,7 @@ class Engine:
         out_offs = torch.cat([out_offs_all[:-1][docs], out_offs_all[-1:]])
         return out_text, out_offs, docs
 
-    SUBSTR_WS_WORDS = 10492939      # MDD_SUBSTR_SORTED_WS_WORDS
+    SUBSTR_WS_WORDS = 11672587      # MDD_SUBSTR_SORTED_WS_WORDS
 
     def substr_dedup(self, text: torch.Tensor, offsets: torch.Tensor, window: int = 50, min_length: int = 20,
                      table_bytes: Optional[int] = None, method: str = "auto"):

@@ -292,3 +292,35 @@ def test_substr_sorted_method_heavy_repetition_and_parts(sorted_method):
     c = engine.substr_dedup(text, offs, 50, 20, method="sorted", table_bytes=int(18 * 1.06 * n_win / 3))
     assert engine.last_substr_parts >= 3
     assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]) and torch.equal(a[0][:n], c[0][:n])
+
+
+def test_substr_sorted_method_big_leaves(sorted_method):
+    """leaves above BIG_LEAF (16384 windows) take the sliced path (bigleaf_kernel: per-slice LDS tables joined through a
+    global table).  Separator lines are the natural source: every window inside a run of one character is the same
+    window.  (a) 60 documents with runs of '-' and '=' plus ordinary text, against the oracle; (b) 30 000 documents
+    (28 M identical windows in one leaf, boilerplate in others), the same survivors as the table method."""
+    import torch
+    engine = sorted_method
+    rng = np.random.Generator(np.random.PCG64(11))
+    words = ["w%d" % i for i in range(40)]
+
+    def doc(i, run):
+        body = " ".join(words[int(x)] for x in rng.integers(0, 40, 30))
+        return body + "\n" + "-" * run + "\n" + body[::-1] + "\n" + "=" * (run // 2) + ("\n%d" % i)
+
+    docs = [doc(i, 700 + 10 * (i % 7)) for i in range(60)]            # 60 x ~670 windows of '-' x 50 = 40 k in one leaf
+    rows = [(d, i) for i, d in enumerate(docs)]
+    assert exact.exact_substr_dedup(engine, rows, 50, 20) == RX.exact_substr_dedup(rows, 50, 20)
+    assert engine.last_substr_method == "sorted"
+    docs = [doc(i, 1000) for i in range(30_000)]
+    enc = [d.encode() for d in docs]
+    offs_h = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in enc], out=offs_h[1:])
+    buf = np.zeros(int(offs_h[-1]) + 3 - (int(offs_h[-1]) + 3) % 4 + 128, dtype=np.uint8)
+    buf[: int(offs_h[-1])] = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    text = torch.from_numpy(buf).to(engine.device)
+    offs = torch.from_numpy(offs_h).to(engine.device)
+    a = engine.substr_dedup(text, offs, 50, 20, method="sorted")
+    b = engine.substr_dedup(text, offs, 50, 20, method="table")
+    n = int(a[1][-1].item())
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0][:n], b[0][:n]) and 0 < n < int(offs[-1].item())
