@@ -187,12 +187,26 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
     so = offsets[: k + 1].contiguous()
     sb = int(so[-1].item())
     ms, (st, so2, sd) = timed(lambda: exact.exact_substr_dedup_packed(eng, text, so, 50, 20), reps=1)
+    n_win = sb - 50 * k
     out["exact_substr_dedup"] = {"ms": ms, "docs": k, "docs_per_s": k / ms * 1e3, "text_gb_per_s": sb / ms / 1e6,
-                                 "windows_per_s": (sb - 50 * k) / ms * 1e3, "bytes_out": int(so2[-1].item()), "docs_out": int(sd.numel()),
-                                 "random_atomics": sb - 50 * k,
-                                 "atomic_floor_ms": (sb - 50 * k) / 17.5e9 * 1e3,
-                                 "note": "one random 8-byte atomicCAS per window; the device sustains ~17.5 G/s of those on "
-                                         "tables >> 256 MB (tools/atomic_ubench.hip), which bounds the stage"}
+                                 "windows_per_s": n_win / ms * 1e3, "bytes_out": int(so2[-1].item()), "docs_out": int(sd.numel()),
+                                 "method": eng.last_substr_method, "passes": eng.last_substr_parts}
+    if eng.last_substr_method == "sorted":
+        # per window: entry written + d1 (10 B), read and rewritten by two scatter levels (2 x 16 B + 2 B), read by the count
+        # pass and by the leaves (16 B), ~15 % of the windows verified on two 64-byte lines; text read by emit and by the
+        # two compaction passes, dup marks written and read, survivors written
+        alg = n_win * (10 + 34 + 16) + int(0.15 * n_win) * 256 + 3 * sb + 3 * sb + int(so2[-1].item())
+        out["exact_substr_dedup"].update({
+            "algorithmic_bytes": alg, "hbm_frac": alg / (ms * 1e-3) / HBM_PEAK,
+            "note": "windows sorted into 2^22 leaves (two LDS-sorted scatter levels) and grouped in LDS, bytes compared on tag "
+                    "matches; bounded by random DRAM accesses (~17.5 G/s): level-1 runs of 6 entries and two text lines per "
+                    "verified window; kernels: emit 15.3, scatter 16.8 + 8.7, count 3.5, leaves 30.5, compaction 12 ms "
+                    "(profiles/r2c_substr_kernels.txt); the table method (one random atomic per window) takes 174 ms"})
+    else:
+        out["exact_substr_dedup"].update({
+            "random_atomics": n_win, "atomic_floor_ms": n_win / 17.5e9 * 1e3,
+            "note": "one random 8-byte atomicCAS per window; the device sustains ~17.5 G/s of those on "
+                    "tables >> 256 MB (tools/atomic_ubench.hip), which bounds the stage"})
     if with_cpu:
         from oracle import ref_exact
         k = 1500
