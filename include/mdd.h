@@ -234,6 +234,13 @@ int mdd_components_finish(mdd_ctx* ctx, uint32_t* labels, uint64_t n_docs);
 int mdd_forest_edges(mdd_ctx* ctx, const uint32_t* labels, uint64_t n_docs, uint32_t* edge_u, uint32_t* edge_v,
                      uint64_t edge_cap, uint64_t* n_edges);
 
+/* Re-verification of candidate pairs from their signatures (an EXTENSION: the reference unions
+ * every bucket pair unverified, EN:136-145).  matches[e] = number of i < K with sig[edge_u[e]][i] == sig[edge_v[e]][i],
+ * i.e. K x datasketch's MinHash.jaccard() of the two documents; an edge naming a document >= n_docs gets 0.  The caller
+ * keeps the edges whose count reaches its threshold before mdd_components_union (map_neo_amd.dedup: min_jaccard). */
+int mdd_signature_matches(mdd_ctx* ctx, const uint32_t* sig, uint64_t n_docs, int K, const uint32_t* edge_u,
+                          const uint32_t* edge_v, uint64_t n_edges, uint32_t* matches);
+
 /* Removal rule.  Replaces EN:145-149 (every non-minimum member of a component is removed)
  * and ZH-4:17-22 (members [1:] of each component): removed[d] = labels[first+d] != first+d for
  * the n documents starting at global index `first`; *n_removed (device u64) = their count. */

@@ -30,7 +30,8 @@ class CheckpointError(RuntimeError):
 
 def params_of(args) -> dict:
     return {"width": int(args.width), "ngram_unit": str(args.ngram_unit), "num_perm": int(args.num_perm), "bands": int(args.bands),
-            "rows": int(args.rows), "seed": int(args.seed)}
+            "rows": int(args.rows), "seed": int(args.seed),
+            **({"min_jaccard": float(args.min_jaccard)} if getattr(args, "min_jaccard", None) is not None else {})}
 
 
 def _atomic_save(path: str, arr: np.ndarray) -> None:

@@ -49,6 +49,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--bands", type=int, default=9)
     p.add_argument("--rows", type=int, default=13)
     p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--min_jaccard", type=float, default=None,
+                   help="extension (the reference has no such step): drop candidate pairs whose signatures agree on fewer than "
+                        "ceil(min_jaccard * num_perm) components before the union-find; one-GPU path only")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
     p.add_argument("--checkpoint_dir", default=None,
@@ -212,7 +215,7 @@ def run(args, engine_factory=None) -> dict:
                 eng.components_finish(lab)
                 labels = as_u32(lab).reshape(n)
             else:
-                out = cluster_local(eng, sig, args.bands, args.rows)
+                out = cluster_local(eng, sig, args.bands, args.rows, min_jaccard=args.min_jaccard)
                 labels = as_u32(out["labels"]).reshape(n)
                 if ckpt_dir:
                     edges = np.ascontiguousarray(np.stack([as_u32(out["edge_u"]), as_u32(out["edge_v"])], axis=1))

@@ -854,6 +854,27 @@ __global__ void __launch_bounds__(256) uf_flatten_kernel(uint32_t* parent, uint6
     __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// matches[e] = #{ i < K : sig[u][i] == sig[v][i] } -- K x datasketch's MinHash.jaccard(u, v).  One wave per edge, 64
+// components per step (both rows coalesced); an edge that names a document outside [0, n_docs) gets 0.
+__global__ void __launch_bounds__(256) sig_match_kernel(const uint32_t* __restrict__ sig, uint64_t n_docs, uint32_t K,
+                                                        const uint32_t* __restrict__ eu, const uint32_t* __restrict__ ev, uint64_t n_edges,
+                                                        uint32_t* __restrict__ matches) {
+    const uint32_t lane = lane_id();
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t e = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; e < n_edges; e += nw) {
+        const uint64_t u = eu[e], v = ev[e];
+        uint32_t cnt = 0;
+        if (u < n_docs && v < n_docs) {
+            const uint32_t* ru = sig + u * K;
+            const uint32_t* rv = sig + v * K;
+            for (uint32_t i = lane; i < K; i += 64) cnt += ru[i] == rv[i] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+        if (lane == 0) matches[e] = cnt;
+    }
+}
+
 __global__ void __launch_bounds__(256) removed_kernel(const uint32_t* labels, uint64_t first, uint64_t n, uint8_t* removed,
                                                       unsigned long long* n_removed) {
     __shared__ unsigned int cnt;
@@ -1416,6 +1437,20 @@ int mdd_forest_edges(mdd_ctx* ctx, const uint32_t* labels, uint64_t n_docs, uint
     REQUIRE(n_docs <= MAX_ELEMS_PER_LAUNCH, "mdd_forest_edges: n_docs exceeds one launch (2^32-256)");
     hipLaunchKernelGGL(forest_edges_kernel, dim3(grid_for(n_docs, 256 * EDGE_TILES)), dim3(256), 0, ctx->stream, labels, n_docs, edge_u,
                        edge_v, edge_cap, reinterpret_cast<unsigned long long*>(n_edges));
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+int mdd_signature_matches(mdd_ctx* ctx, const uint32_t* sig, uint64_t n_docs, int K, const uint32_t* edge_u,
+                          const uint32_t* edge_v, uint64_t n_edges, uint32_t* matches) {
+    REQUIRE(ctx, "mdd_signature_matches: ctx is NULL");
+    REQUIRE(K >= 1 && K <= 4096, "mdd_signature_matches: K=%d outside [1,4096]", K);
+    if (n_edges == 0) return MDD_OK;
+    REQUIRE(sig && edge_u && edge_v && matches, "mdd_signature_matches: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint64_t blocks = (n_edges + 3) / 4, cap = (uint64_t)ctx->cus * 64;
+    hipLaunchKernelGGL(sig_match_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, ctx->stream, sig, n_docs, (uint32_t)K,
+                       edge_u, edge_v, n_edges, matches);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

@@ -42,16 +42,29 @@ class StageTimer:
         return out
 
 
+def verified_edges(be, sig: torch.Tensor, eu: torch.Tensor, ev: torch.Tensor, min_jaccard: float):
+    """The edges whose two documents agree on at least ceil(min_jaccard * K) signature components (datasketch's
+    MinHash.jaccard() >= min_jaccard).  An extension: the reference has no such step (EN:136-145 unions every pair)."""
+    import math
+    need = int(math.ceil(float(min_jaccard) * sig.shape[1] - 1e-9))
+    keep = be.signature_matches(sig, eu, ev) >= need
+    return eu[keep], ev[keep]
+
+
 def cluster_local(be, sig: torch.Tensor, bands: int = BANDS, rows: int = ROWS, key_bits: int = 64,
-                  want_buckets: bool = False, timer: Optional[StageTimer] = None):
+                  want_buckets: bool = False, timer: Optional[StageTimer] = None, min_jaccard: Optional[float] = None):
     """Band records -> buckets/edges -> union-find -> removed mask for signatures already in HBM
-    (EN:133-145 / ZH-2..ZH-4).  Document index = row of `sig`."""
+    (EN:133-145 / ZH-2..ZH-4).  Document index = row of `sig`.  min_jaccard (default None = the reference's behaviour)
+    drops candidate edges (document, smallest document of its bucket) whose estimated Jaccard similarity is lower."""
     n, num_perm = sig.shape
     mark = timer.mark if timer is not None else (lambda name: None)
     key, meta = be.band_keys(sig, bands, rows, 0, key_bits)
     mark("band_keys")
     eu, ev, n_coll, rb = be.bucket_edges(key, meta, sig, bands, num_perm, rows, rows, want_buckets)
     mark("bucket_edges")
+    if min_jaccard is not None:
+        eu, ev = verified_edges(be, sig, eu, ev, min_jaccard)
+        mark("verify")
     labels = be.components_init(n)
     be.components_union(labels, eu, ev)
     be.components_finish(labels)
@@ -65,7 +78,7 @@ def cluster_local(be, sig: torch.Tensor, bands: int = BANDS, rows: int = ROWS, k
 def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = NUM_PERM, width: int = WIDTH,
                 unit: str = "char", bands: int = BANDS, rows: int = ROWS, seed: int = SEED,
                 text_bytes: Optional[int] = None, key_bits: int = 64, want_buckets: bool = False,
-                timer: Optional[StageTimer] = None):
+                timer: Optional[StageTimer] = None, min_jaccard: Optional[float] = None):
     """One-GPU path.  Returns a dict of device tensors: sig [n,K], edge_u/edge_v, labels [n]
     (label = smallest doc index of the component), removed [n] uint8, n_removed (device
     int64[1]), n_collisions (host int)."""
@@ -73,7 +86,7 @@ def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = N
     mark("start")
     sig = be.signatures(text, offsets, num_perm, width, unit, seed, text_bytes=text_bytes)
     mark("signatures")
-    return cluster_local(be, sig, bands, rows, key_bits, want_buckets, timer)
+    return cluster_local(be, sig, bands, rows, key_bits, want_buckets, timer, min_jaccard)
 
 
 # RCCL on this stack silently drops the tail of an all_to_all_single message beyond 1 GiB (measured with one rank:
@@ -217,7 +230,25 @@ def default_comm(be, group=None):
         return TorchComm(group)
     comm = getattr(be, "_native_comm", None)
     if comm is None:
-        comm = be._native_comm = NativeComm(be, group)
+        # RCCL must be loadable on EVERY rank before any rank enters ncclCommInitRank (a rank that cannot load it would
+        # leave the others waiting there for ever): probe locally, agree, and only then initialise.  Without agreement
+        # all ranks take torch.distributed's RCCL communicator instead -- loudly; it is the same library and the same
+        # wire traffic, issued from Python.
+        ok, why = 1, ""
+        try:
+            be.comm_unique_id()
+        except Exception as e:      # noqa: BLE001 -- whatever went wrong, the other ranks must hear of it
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=be.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            import sys
+            print("map_neo_amd: libmdd_hip could not bind RCCL on every rank (%s): the exchanges go through "
+                  "torch.distributed on this run" % (why or "another rank failed"), file=sys.stderr, flush=True)
+            comm = TorchComm(group)
+        else:
+            comm = NativeComm(be, group)
+        be._native_comm = comm
     return comm
 
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mdd_components_union": (_int, [_vp, _vp, _u64, _vp, _vp, _u64]),
     "mdd_components_finish": (_int, [_vp, _vp, _u64]),
     "mdd_forest_edges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _vp]),
+    "mdd_signature_matches": (_int, [_vp, _vp, _u64, _int, _vp, _vp, _u64, _vp]),
     "mdd_removed_mask": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "mdd_para_count": (_int, [_vp, _vp, _u64, _vp, _u64, _vp]),
     "mdd_para_units": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),

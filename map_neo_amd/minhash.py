@@ -310,6 +310,15 @@ class Engine:
     def components_finish(self, labels: torch.Tensor):
         _lib.check(self.L.mdd_components_finish(self.ctx, _ptr(labels), labels.numel()), "mdd_components_finish")
 
+    def signature_matches(self, sig: torch.Tensor, eu: torch.Tensor, ev: torch.Tensor) -> torch.Tensor:
+        """int32 [n_edges]: equal signature components of the two documents of every edge (K x MinHash.jaccard)."""
+        n, K = sig.shape
+        assert eu.numel() == ev.numel()
+        out = self.empty(max(1, eu.numel()), torch.int32)
+        _lib.check(self.L.mdd_signature_matches(self.ctx, _ptr(sig), n, K, _ptr(eu), _ptr(ev), eu.numel(), _ptr(out)),
+                   "mdd_signature_matches")
+        return out[: eu.numel()]
+
     def forest_edges(self, labels: torch.Tensor, max_edges: int):
         """(d, labels[d]) for every non-root d of flattened labels; max_edges bounds the output."""
         cap = max(1, int(max_edges))

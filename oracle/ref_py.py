@@ -253,6 +253,14 @@ def large_star_small_star(edges: Iterable[tuple]) -> set:
             return a
 
 
+def signature_matches(sigs: np.ndarray, eu: Sequence[int], ev: Sequence[int]) -> np.ndarray:
+    """Number of equal signature components of the documents of every edge = K x datasketch's
+    `MinHash.jaccard(other)` (published algorithm: `np.count_nonzero(self.hashvalues == other.hashvalues) / len(self)`).
+    An extension of the build: the reference scripts never call it."""
+    sigs = np.asarray(sigs)
+    return np.array([int(np.count_nonzero(sigs[int(u)] == sigs[int(v)])) for u, v in zip(eu, ev)], dtype=np.uint32)
+
+
 def components_min_label(n: int, edges: Iterable[tuple]) -> np.ndarray:
     """Connected components with label = minimum doc index of the component (what the EN
     star loop converges to, EN:145; a legal outcome of ZH-3/ZH-4)."""

@@ -86,6 +86,10 @@ class OracleBackend:
         labels.copy_(torch.from_numpy(lab.view(np.int32)))
         self._edges = []
 
+    def signature_matches(self, sig, eu, ev):
+        m = R.signature_matches(sig.numpy().view(np.uint32), eu.numpy().view(np.uint32), ev.numpy().view(np.uint32))
+        return torch.from_numpy(m.astype(np.int32))
+
     def forest_edges(self, labels, max_edges):
         lab = labels.numpy().view(np.uint32)
         idx = np.flatnonzero(lab != np.arange(lab.shape[0], dtype=np.uint32)).astype(np.uint32)

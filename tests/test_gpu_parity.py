@@ -530,3 +530,44 @@ def test_c5_boilerplate_heavy_corpus_vs_oracle(engine):
         assert int(out["n_removed"].item()) == int((exp_labels != np.arange(spec.n_docs)).sum())
         biggest = max(biggest, int(np.bincount(exp_labels).max()))
     assert biggest >= 30          # the popular templates really formed big clusters
+
+
+def test_signature_matches_and_min_jaccard_vs_oracle(engine):
+    """mdd_signature_matches (K x MinHash.jaccard of candidate pairs; an extension) == the oracle's count,
+    incl. K not a multiple of 64, self-pairs, all-max signatures and an out-of-range document; and dedup_local(min_jaccard=t)
+    == the oracle's components over the edges whose count reaches ceil(t K)."""
+    rng = np.random.Generator(np.random.PCG64(123))
+    for K in (128, 256, 100, 1):
+        n = 500
+        base = rng.integers(0, 2 ** 32, (n, K), dtype=np.uint64).astype(np.uint32)
+        for d in range(1, n, 3):                                  # every third row copies a share of its predecessor
+            keep = rng.random(K) < rng.random()
+            base[d, keep] = base[d - 1, keep]
+        base[7] = 0xFFFFFFFF
+        base[8] = 0xFFFFFFFF
+        eu = rng.integers(0, n, 4000).astype(np.uint32)
+        ev = np.where(rng.random(4000) < 0.5, np.maximum(eu, 1) - 1, rng.integers(0, n, 4000)).astype(np.uint32)
+        eu[:3], ev[:3] = (7, 5, 9), (8, 5, 9)
+        sig = engine.to_device(base)
+        got = as_u32(engine.signature_matches(sig, engine.to_device(eu), engine.to_device(ev)))
+        assert np.array_equal(got, R.signature_matches(base, eu, ev)), K
+        assert got[0] == K and got[1] == K
+    bad = engine.signature_matches(sig, engine.to_device(np.array([0, n], np.uint32)), engine.to_device(np.array([0, 0], np.uint32)))
+    assert as_u32(bad).tolist() == [1, 0]
+    assert engine.signature_matches(sig, engine.to_device(np.zeros(0, np.uint32)), engine.to_device(np.zeros(0, np.uint32))).numel() == 0
+    # end to end: near-duplicates at several edit rates; the threshold sits above the weakest candidate pairs, so it does cut
+    spec = corpus.CorpusSpec(3000, 600, lang="mixed", seed=77, dup_frac=0.3, edit_rates=(0.01, 0.05, 0.1, 0.2, 0.4))
+    text, offs = corpus.generate(spec, device=engine.device)
+    plain = dedup_local(engine, text, offs)
+    sigs = as_u32(plain["sig"]).reshape(spec.n_docs, -1)
+    eu, ev = as_u32(plain["edge_u"]), as_u32(plain["edge_v"])
+    m = R.signature_matches(sigs, eu, ev)
+    K = sigs.shape[1]
+    assert int(m.min()) < K                                      # some candidate pair is not an exact signature match
+    need = min(K, int(np.sort(m)[len(m) // 4]) + 1)               # above the lowest quarter, so the threshold does cut
+    t = need / K
+    res = dedup_local(engine, text, offs, min_jaccard=t)
+    kept = [(int(u), int(v)) for u, v, c in zip(eu, ev, m) if c >= need]
+    assert 0 < len(kept) < len(eu)
+    assert np.array_equal(as_u32(res["labels"]), R.components_min_label(spec.n_docs, kept))
+    assert int(res["n_removed"].item()) < int(plain["n_removed"].item())
