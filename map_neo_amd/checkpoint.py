@@ -93,8 +93,8 @@ def load(directory: str, stage: str, params: dict) -> dict:
         man = json.load(f)
     if man.get("version") != 1 or "artifacts" not in man:
         raise CheckpointError(f"{mpath}: unknown manifest format")
-    keys = ("width", "ngram_unit", "num_perm", "seed") if stage == "signatures" else tuple(params)
-    diff = {k: (man["params"].get(k), params[k]) for k in keys if man["params"].get(k) != params[k]}
+    keys = ("width", "ngram_unit", "num_perm", "seed") if stage == "signatures" else sorted(set(params) | set(man["params"]))
+    diff = {k: (man["params"].get(k), params.get(k)) for k in keys if man["params"].get(k) != params.get(k)}
     if diff:
         raise CheckpointError(f"{mpath} was written with other parameters (manifest, now): {diff}")
     if stage not in man["artifacts"]:
