@@ -197,7 +197,7 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
         # two compaction passes, dup marks written and read, survivors written
         alg = n_win * (10 + 34 + 16) + int(0.15 * n_win) * 256 + 3 * sb + 3 * sb + int(so2[-1].item())
         out["exact_substr_dedup"].update({
-            "algorithmic_bytes": alg, "hbm_frac": alg / (ms * 1e-3) / HBM_PEAK,
+            "algorithmic_bytes": alg, "hbm_frac": alg / ms / 1e6 / HBM,
             "note": "windows sorted into 2^22 leaves (two LDS-sorted scatter levels) and grouped in LDS, bytes compared on tag "
                     "matches; bounded by random DRAM accesses (~17.5 G/s): level-1 runs of 6 entries and two text lines per "
                     "verified window; kernels: emit 15.3, scatter 16.8 + 8.7, count 3.5, leaves 30.5, compaction 12 ms "

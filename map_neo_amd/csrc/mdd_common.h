@@ -57,6 +57,19 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
     return x;
 }
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// The low nb (0..4) bytes of v to out[pos ..), nothing at or beyond cap.  Four bytes go out as ONE dword store at a byte
+// address (the target runs with unaligned global access enabled -- the compiler itself relies on it and emits a single
+// global_store_dword here); the write kernels with a dword per lane depend on this: 64 lanes x 4 consecutive bytes.
+typedef uint32_t mdd_u32_a1 __attribute__((aligned(1)));
+__device__ __forceinline__ void store_low_bytes(uint8_t* __restrict__ out, uint64_t pos, uint64_t cap, uint32_t v, uint32_t nb) {
+    if (nb == 4u && pos + 4 <= cap) {
+        *reinterpret_cast<mdd_u32_a1*>(out + pos) = v;
+        return;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+        if (k < nb && pos + k < cap) out[pos + k] = (uint8_t)(v >> (8 * k));
+}
 __device__ __forceinline__ uint32_t below(uint64_t m) {  // set bits of m in lanes below this one
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }

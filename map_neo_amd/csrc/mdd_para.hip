@@ -264,6 +264,107 @@ __global__ void __launch_bounds__(256) para_compact_count4_kernel(const uint8_t*
     }
 }
 
+// Write pass with a dword per lane.  Per byte the rules are those of para_compact_kernel: a byte that is not a newline goes out
+// with its paragraph; a newline goes out when the paragraph AFTER it survives and a surviving paragraph has ended at or
+// before it ("\n".join of the survivors).  A lane knows the paragraph of its first byte from 3 ballots over the lanes' newline
+// counts, looks up the verdicts of the (at most 5) paragraphs its 4 bytes touch, and learns from one more ballot whether a
+// survivor ended in a lane below it; its kept bytes (0..4) are placed by 3 ballots over the counts and leave as one
+// unaligned dword store when all four are kept.
+__global__ void __launch_bounds__(256) para_compact_write4_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                                  const uint64_t* __restrict__ offs, uint64_t n,
+                                                                  const uint64_t* __restrict__ unit_base, uint64_t n_units,
+                                                                  const uint32_t* __restrict__ first_of, const uint8_t* __restrict__ keep_doc,
+                                                                  const uint64_t* __restrict__ out_offs, uint8_t* __restrict__ out_text,
+                                                                  uint64_t out_cap) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
+    auto kept_unit = [&](uint64_t u) -> bool { return u < n_units && first_of[u] == (uint32_t)u; };
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        if (!keep_doc[d]) continue;
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        const uint64_t w0 = b >> 2, w1 = b < e ? (e + 3) >> 2 : w0;
+        uint64_t u = unit_base[d];
+        uint64_t done = out_offs[d];  // next output position of the wave
+        bool any = false;             // a surviving paragraph ended in an earlier step
+        for (uint64_t wi = w0; wi < w1; wi += 128) {
+            uint32_t ww[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                ww[j] = i < w1 ? tw[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                const uint64_t p = i << 2;
+                const uint32_t w = ww[j];
+                uint32_t in = i < w1 ? 0x80808080u : 0u;  // bytes of the dword inside [b, e), as bit 7 of each byte
+                if (p < b || p + 4 > e) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (p + k < b || p + k >= e) in &= ~(0x80u << (8 * k));
+                }
+                const uint32_t y = w ^ 0x0A0A0A0Au;
+                const uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu) & in;  // '\n' bytes
+                const uint32_t c = (uint32_t)__builtin_popcount(z);
+                const uint64_t B0 = __ballot(c & 1u), B1 = __ballot(c & 2u), B2 = __ballot(c & 4u);
+                const uint64_t cur = u + __builtin_popcountll(B0 & lt) + 2 * __builtin_popcountll(B1 & lt) +
+                                     4 * __builtin_popcountll(B2 & lt);  // paragraph of the lane's first byte
+                // verdicts of the paragraphs cur .. cur + c (bit q = paragraph cur + q survives)
+                uint32_t ku = (in != 0u && kept_unit(cur)) ? 1u : 0u;
+                if (c) {
+#pragma unroll
+                    for (uint32_t q = 1; q <= 4; q++)
+                        if (q <= c && kept_unit(cur + q)) ku |= 1u << q;
+                }
+                const bool ends_surv = (ku & ((1u << c) - 1u)) != 0u;  // one of the lane's newlines ends a survivor
+                const uint64_t BA = __ballot(ends_surv);
+                bool a = any || (BA & lt) != 0;
+                uint32_t keep = 0;  // bit 7 of each kept byte
+                if (c == 0u) {
+                    if (ku & 1u) keep = in;
+                } else {
+                    uint32_t q = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t f = 0x80u << (8 * k);
+                        if (z & f) {
+                            a = a || ((ku >> q) & 1u);
+                            q++;
+                            if (((ku >> q) & 1u) && a) keep |= f;
+                        } else if ((in & f) && ((ku >> q) & 1u)) {
+                            keep |= f;
+                        }
+                    }
+                }
+                const uint32_t kc = (uint32_t)__builtin_popcount(keep);
+                const uint64_t K0 = __ballot(kc & 1u), K1 = __ballot(kc & 2u), K2 = __ballot(kc & 4u);
+                if (kc) {
+                    const uint64_t pos = done + __builtin_popcountll(K0 & lt) + 2 * __builtin_popcountll(K1 & lt) + 4 * __builtin_popcountll(K2 & lt);
+                    uint32_t v = w;
+                    if (kc != 4u) {  // squeeze the kept bytes together
+                        v = 0;
+                        uint32_t at = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (keep & (0x80u << (8 * k))) {
+                                v |= ((w >> (8 * k)) & 0xFFu) << (8 * at);
+                                at++;
+                            }
+                    }
+                    store_low_bytes(out_text, pos, out_cap, v, kc);  // out_offsets are the caller's: stay inside out_text
+                }
+                done += __builtin_popcountll(K0) + 2 * __builtin_popcountll(K1) + 4 * __builtin_popcountll(K2);
+                any = any || BA != 0;
+                u += __builtin_popcountll(B0) + 2 * __builtin_popcountll(B1) + 4 * __builtin_popcountll(B2);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mdd_para_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
@@ -326,9 +427,13 @@ extern "C" int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_
     REQUIRE(offsets && unit_base && first_of && keep_doc && out_offsets && ((text && out_text) || text_bytes == 0),
             "mdd_para_compact_write: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(para_compact_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
-                       n_docs, unit_base, n_units, first_of, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr, keep_doc,
-                       out_offsets, out_text, out_capacity);
+    if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)  // the usual case (device allocations are aligned): dword per lane
+        hipLaunchKernelGGL(para_compact_write4_kernel, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, unit_base, n_units, first_of, keep_doc, out_offsets, out_text, out_capacity);
+    else
+        hipLaunchKernelGGL(para_compact_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, unit_base, n_units, first_of, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr, keep_doc,
+                           out_offsets, out_text, out_capacity);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

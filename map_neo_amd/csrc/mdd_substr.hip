@@ -216,6 +216,142 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict_
     }
 }
 
+// The same pass with a dword per lane (text and dup 4-byte aligned): a wave step covers 256 bytes.  Per lane: flags of its
+// code-point starts S and marked starts M (SWAR on the text / dup dwords).  Across lanes: the number of starts below a lane
+// (3 ballots over the lanes' counts), the start index of the most recent mark below it (one ballot + one shuffle), whether
+// the last start below it is gone (two ballots) -- 6 ballots per 256 bytes where the byte-per-lane pass needs 16 -- and,
+// for the write pass, the kept bytes below it (3 more).  Kept bytes leave as one unaligned dword store when all four stay.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) compact4_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                       const uint64_t* __restrict__ offs, uint64_t n, const uint8_t* __restrict__ dup,
+                                                       uint32_t W, uint64_t* kept_bytes, uint64_t* kept_cps,
+                                                       const uint8_t* __restrict__ keep_doc, const uint64_t* __restrict__ out_offs,
+                                                       uint8_t* __restrict__ out_text, uint64_t out_cap) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
+    const uint32_t* __restrict__ dw = reinterpret_cast<const uint32_t*>(dup);
+    auto sat_add = [](uint32_t x, uint32_t add) -> uint32_t { return x > 0x7FFFFFFFu - add ? 0x7FFFFFFFu : x + add; };
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        if (WRITE && !keep_doc[d]) continue;
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        const uint64_t w0 = b >> 2, w1 = b < e ? (e + 3) >> 2 : w0;
+        uint64_t done = WRITE ? out_offs[d] : 0;  // write pass: next output position of the wave
+        uint32_t cnt_b = 0, cnt_c = 0;            // count pass: per-lane sums
+        uint32_t since = 0x7FFFFFFFu;             // starts since the most recent marked start, at the end of the previous step
+        bool carry_gone = false;
+        for (uint64_t wi = w0; wi < w1; wi += 128) {
+            uint32_t ww[2], dd[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                ww[j] = i < w1 ? tw[i] : 0u;  // (the text's last dword lies inside MDD_TEXT_PAD)
+                dd[j] = 0u;
+                if (i < w1) {
+                    if ((i + 1) * 4 <= text_bytes) {
+                        dd[j] = dw[i];
+                    } else {  // dup is exactly text_bytes long: its last, partial dword byte by byte
+                        for (uint64_t q = i * 4; q < text_bytes; q++) dd[j] |= (uint32_t)dup[q] << (8 * (q - i * 4));
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                const uint64_t p = i << 2;
+                const uint32_t w = ww[j], du = dd[j];
+                uint32_t in = i < w1 ? 0x80808080u : 0u;  // bytes of the dword inside [b, e), as bit 7 of each byte
+                if (p < b || p + 4 > e) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (p + k < b || p + k >= e) in &= ~(0x80u << (8 * k));
+                }
+                const uint32_t cb = w & ~(w << 1) & 0x80808080u;                                    // continuation bytes (10xxxxxx)
+                const uint32_t S = in & ~cb;                                                        // code-point starts
+                const uint32_t nz = (((du & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | du) & 0x80808080u;        // dup bytes != 0
+                const uint32_t M = S & nz;                                                          // marked window starts
+                const uint32_t s = (uint32_t)__builtin_popcount(S);
+                const uint64_t B0 = __ballot(s & 1u), B1 = __ballot(s & 2u), B2 = __ballot(s & 4u);
+                const uint32_t P = (uint32_t)(__builtin_popcountll(B0 & lt) + 2 * __builtin_popcountll(B1 & lt) + 4 * __builtin_popcountll(B2 & lt));
+                const uint32_t T = (uint32_t)(__builtin_popcountll(B0) + 2 * __builtin_popcountll(B1) + 4 * __builtin_popcountll(B2));
+                // index (1-based among the step's starts) of this lane's last marked start, and of the last one below this lane
+                const bool has_m = M != 0u;
+                const uint32_t last_m = has_m ? 31u - (uint32_t)__builtin_clz(M) : 0u;
+                const uint32_t Vm = P + (uint32_t)__builtin_popcount(S & (0xFFFFFFFFu >> (31u - last_m)));
+                const uint64_t BM = __ballot(has_m);
+                const uint64_t pm = BM & lt;
+                const bool have_prev = pm != 0;
+                const uint32_t Vprev = (uint32_t)__shfl((int)Vm, have_prev ? 63 - __builtin_clzll(pm) : 0, 64);
+                // which of the lane's starts are gone: fewer than W starts since the most recent marked one
+                uint32_t gs = 0, rank = 0, mr = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t f = 0x80u << (8 * k);
+                    if (S & f) {
+                        rank++;
+                        if (M & f) mr = rank;
+                        const uint32_t sc = mr ? rank - mr : (have_prev ? P + rank - Vprev : sat_add(since, P + rank));
+                        if (sc < W) gs |= f;
+                    }
+                }
+                // a continuation byte shares the fate of its code point's start, which may lie in a lane below or in the previous step
+                const bool has_s = S != 0u;
+                const bool g_last = has_s && ((gs >> (31u - (uint32_t)__builtin_clz(S | 1u))) & 1u);
+                const uint64_t BS = __ballot(has_s), BG = __ballot(g_last);
+                const uint64_t ps = BS & lt;
+                bool g = ps ? ((BG >> (63 - __builtin_clzll(ps))) & 1) : carry_gone;
+                uint32_t keep = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t f = 0x80u << (8 * k);
+                    if (S & f) g = (gs & f) != 0u;
+                    if ((in & f) && !g) keep |= f;
+                }
+                const uint32_t kc = (uint32_t)__builtin_popcount(keep);
+                if (WRITE) {
+                    const uint64_t K0 = __ballot(kc & 1u), K1 = __ballot(kc & 2u), K2 = __ballot(kc & 4u);
+                    if (kc) {
+                        const uint64_t pos = done + __builtin_popcountll(K0 & lt) + 2 * __builtin_popcountll(K1 & lt) + 4 * __builtin_popcountll(K2 & lt);
+                        uint32_t v = w;
+                        if (kc != 4u) {  // squeeze the kept bytes together
+                            v = 0;
+                            uint32_t at = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (keep & (0x80u << (8 * k))) {
+                                    v |= ((w >> (8 * k)) & 0xFFu) << (8 * at);
+                                    at++;
+                                }
+                        }
+                        store_low_bytes(out_text, pos, out_cap, v, kc);  // out_offsets are the caller's: stay inside out_text
+                    }
+                    done += __builtin_popcountll(K0) + 2 * __builtin_popcountll(K1) + 4 * __builtin_popcountll(K2);
+                } else {
+                    cnt_b += kc;
+                    cnt_c += (uint32_t)__builtin_popcount(keep & S);
+                }
+                // carries into the next step
+                if (BM) since = T - (uint32_t)__shfl((int)Vm, 63 - __builtin_clzll(BM), 64);
+                else since = sat_add(since, T);
+                if (BS) carry_gone = (BG >> (63 - __builtin_clzll(BS))) & 1;
+            }
+        }
+        if (!WRITE) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                cnt_b += (uint32_t)__shfl_xor((int)cnt_b, o, 64);
+                cnt_c += (uint32_t)__shfl_xor((int)cnt_c, o, 64);
+            }
+            if (lane == 0) {
+                kept_bytes[d] = cnt_b;
+                kept_cps[d] = cnt_c;
+            }
+        }
+    }
+}
+
 unsigned compact_grid(const mdd_ctx* ctx, uint64_t n) {
     uint64_t blocks = (n + 3) / 4, cap = (uint64_t)ctx->cus * 64;
     return (unsigned)(blocks < cap ? blocks : cap);
@@ -296,9 +432,14 @@ extern "C" int mdd_substr_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text
     if (n_docs == 0) return MDD_OK;
     REQUIRE(offsets && kept_bytes && kept_cps && ((text && dup) || text_bytes == 0), "mdd_substr_count: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(compact_kernel<false>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
-                       n_docs, dup, (uint32_t)window, kept_bytes, kept_cps, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
-                       (uint8_t*)nullptr, (uint64_t)0);
+    if (((reinterpret_cast<uintptr_t>(text) | reinterpret_cast<uintptr_t>(dup)) & 3u) == 0)  // the usual case: dword per lane
+        hipLaunchKernelGGL(compact4_kernel<false>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, dup, (uint32_t)window, kept_bytes, kept_cps, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
+                           (uint8_t*)nullptr, (uint64_t)0);
+    else
+        hipLaunchKernelGGL(compact_kernel<false>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, dup, (uint32_t)window, kept_bytes, kept_cps, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
+                           (uint8_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
@@ -311,9 +452,14 @@ extern "C" int mdd_substr_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text
     if (n_docs == 0) return MDD_OK;
     REQUIRE(offsets && keep_doc && out_offsets && ((text && dup && out_text) || text_bytes == 0), "mdd_substr_write: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(compact_kernel<true>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
-                       n_docs, dup, (uint32_t)window, (uint64_t*)nullptr, (uint64_t*)nullptr, keep_doc, out_offsets, out_text,
-                       out_capacity);
+    if (((reinterpret_cast<uintptr_t>(text) | reinterpret_cast<uintptr_t>(dup)) & 3u) == 0)
+        hipLaunchKernelGGL(compact4_kernel<true>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, dup, (uint32_t)window, (uint64_t*)nullptr, (uint64_t*)nullptr, keep_doc, out_offsets, out_text,
+                           out_capacity);
+    else
+        hipLaunchKernelGGL(compact_kernel<true>, dim3(compact_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
+                           n_docs, dup, (uint32_t)window, (uint64_t*)nullptr, (uint64_t*)nullptr, keep_doc, out_offsets, out_text,
+                           out_capacity);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict_
     }
 }
 
-// Count pass, dword per lane (text 4-byte aligned): a lane owns 4 consecutive bytes, a wave step covers 256.
+// Count and write passes, dword per lane (text 4-byte aligned): a lane owns 4 consecutive bytes, a wave step covers 256.
 // The byte classes come from SWAR range tests on the whole dword (bytes are < 0x80 in every document that
 // survives, so x + (128 - lo) and x + (127 - hi) never carry into the neighbour byte; bit 7 of a byte then
 // says x >= lo resp. x > hi).  Inside the lane the "previous kept byte is whitespace" / "a word was seen"
@@ -89,18 +89,25 @@ __device__ __forceinline__ uint32_t swar_in_range(uint32_t x7, uint32_t lo, uint
     return (x7 + (128u - lo) * 0x01010101u) & ~(x7 + (127u - hi) * 0x01010101u) & 0x80808080u;
 }
 
-__global__ void __launch_bounds__(256) norm_en_count4_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
-                                                             const uint64_t* __restrict__ offs, uint64_t n, uint64_t* out_len,
-                                                             uint8_t* non_ascii) {
+// WRITE: the same walk, second time: the bytes of non-flagged documents go out.  A lane emits 0..8 bytes per step (each of
+// its 4 bytes, and the single space before a word); its first output position = the document's offset + what earlier
+// steps wrote + the counts of the lanes below it, which four ballots over the bits of the count deliver.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) norm_en4_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes,
+                                                       const uint64_t* __restrict__ offs, uint64_t n, uint64_t* out_len,
+                                                       uint8_t* non_ascii, const uint64_t* __restrict__ out_offs,
+                                                       uint8_t* __restrict__ out_text, uint64_t out_cap) {
     const uint32_t lane = lane_id();
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;  // lanes below this one
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
     for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        if (WRITE && non_ascii[d]) continue;
         uint64_t b, e;
         doc_range(offs, d, text_bytes, b, e);
         const uint64_t w0 = b >> 2, w1 = (e + 3) >> 2;  // dwords that hold the document (the last one lies inside the text's padding)
-        uint32_t cnt = 0;
+        uint64_t done = WRITE ? out_offs[d] : 0;      // WRITE: next output position of the wave (wave-uniform)
+        uint32_t cnt = 0;                             // count pass: this lane's bytes, summed once per document
         bool carry_ws = false, carry_seen = false, bad = false;  // wave-uniform carries between steps
         for (uint64_t wi = w0; wi < w1 && !bad; wi += 128) {
             uint32_t ww[2];  // two independent loads in flight
@@ -119,7 +126,7 @@ __global__ void __launch_bounds__(256) norm_en_count4_kernel(const uint8_t* __re
                 for (int k = 0; k < 4; k++)
                     if (i < w1 && p + k >= b && p + k < e) in |= 0x80u << (8 * k);
                 const uint32_t w = ww[j];
-                if (__ballot((w & in) != 0u)) {  // a byte >= 0x80: the document goes to the Python steps
+                if (!WRITE && __ballot((w & in) != 0u)) {  // a byte >= 0x80: the document goes to the Python steps
                     bad = true;
                     break;
                 }
@@ -127,6 +134,7 @@ __global__ void __launch_bounds__(256) norm_en_count4_kernel(const uint8_t* __re
                 const uint32_t punct = swar_in_range(x, 33, 47) | swar_in_range(x, 58, 64) | swar_in_range(x, 91, 96) |
                                        swar_in_range(x, 123, 126);
                 const uint32_t space = swar_in_range(x, 9, 13) | swar_in_range(x, 28, 32);
+                const uint32_t upper = swar_in_range(x, 65, 90);
                 const uint32_t K = in & ~punct, W = K & space, N = K & ~W;
                 // lane summary for the cross-lane state
                 const bool has_k = K != 0u, has_n = N != 0u;
@@ -136,27 +144,60 @@ __global__ void __launch_bounds__(256) norm_en_count4_kernel(const uint8_t* __re
                 const uint64_t pk = BK & lt;
                 bool pw = pk ? ((BW >> (63 - __builtin_clzll(pk))) & 1) : carry_ws;  // previous kept byte is whitespace
                 bool sn = carry_seen || (BN & lt);                                      // a non-whitespace byte was seen
+                if (!WRITE) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t f = 0x80u << (8 * k);
-                    if (N & f) {
-                        cnt += 1u + ((pw && sn) ? 1u : 0u);  // the byte, and the single space before it
-                        sn = true;
-                        pw = false;
-                    } else if (W & f) {
-                        pw = true;
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t f = 0x80u << (8 * k);
+                        if (N & f) {
+                            cnt += 1u + ((pw && sn) ? 1u : 0u);  // the byte, and the single space before it
+                            sn = true;
+                            pw = false;
+                        } else if (W & f) {
+                            pw = true;
+                        }
                     }
+                } else {
+                    // what this lane emits, lower-cased (A-Z | 0x20), as up to 8 bytes in two dwords
+                    const uint32_t lowered = x | (upper >> 2);
+                    uint32_t lo = 0, hi = 0, c = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t f = 0x80u << (8 * k);
+                        if (N & f) {
+                            if (pw && sn) {
+                                if (c < 4) lo |= 0x20u << (8 * c);
+                                else hi |= 0x20u << (8 * (c - 4));
+                                c++;
+                            }
+                            const uint32_t ch = (lowered >> (8 * k)) & 0xFFu;
+                            if (c < 4) lo |= ch << (8 * c);
+                            else hi |= ch << (8 * (c - 4));
+                            c++;
+                            sn = true;
+                            pw = false;
+                        } else if (W & f) {
+                            pw = true;
+                        }
+                    }
+                    const uint64_t c0 = __ballot(c & 1u), c1 = __ballot(c & 2u), c2 = __ballot(c & 4u), c3 = __ballot(c & 8u);
+                    uint64_t pos = done + __builtin_popcountll(c0 & lt) + 2 * __builtin_popcountll(c1 & lt) + 4 * __builtin_popcountll(c2 & lt) +
+                                   8 * __builtin_popcountll(c3 & lt);
+                    store_low_bytes(out_text, pos, out_cap, lo, c < 4u ? c : 4u);  // out_offsets are the caller's: stay inside out_text
+                    if (c > 4u) store_low_bytes(out_text, pos + 4, out_cap, hi, c - 4u);
+                    done += __builtin_popcountll(c0) + 2 * __builtin_popcountll(c1) + 4 * __builtin_popcountll(c2) + 8 * __builtin_popcountll(c3);
                 }
                 if (BK) carry_ws = (BW >> (63 - __builtin_clzll(BK))) & 1;
                 carry_seen = carry_seen || BN;
             }
         }
-        uint32_t tot = cnt;
+        if (!WRITE) {
+            uint32_t tot = cnt;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
-        if (lane == 0) {
-            out_len[d] = bad ? 0 : tot;
-            non_ascii[d] = bad;
+            for (int o = 32; o >= 1; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+            if (lane == 0) {
+                out_len[d] = bad ? 0 : tot;
+                non_ascii[d] = bad;
+            }
         }
     }
 }
@@ -220,8 +261,8 @@ extern "C" int mdd_normalize_en_count(mdd_ctx* ctx, const uint8_t* text, uint64_
     REQUIRE(text && offsets && out_len && non_ascii, "mdd_normalize_en_count: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)  // the usual case (device allocations are aligned): dword per lane
-        hipLaunchKernelGGL(norm_en_count4_kernel, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
-                           out_len, non_ascii);
+        hipLaunchKernelGGL(norm_en4_kernel<false>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
+                           out_len, non_ascii, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
     else
         hipLaunchKernelGGL(norm_en_kernel<false>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
                            n_docs, out_len, non_ascii, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
@@ -235,8 +276,12 @@ extern "C" int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, uint64_
     if (n_docs == 0) return MDD_OK;
     REQUIRE(text && offsets && non_ascii && out_offsets && out_text, "mdd_normalize_en_write: NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(norm_en_kernel<true>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
-                       (uint64_t*)nullptr, const_cast<uint8_t*>(non_ascii), out_offsets, out_text, out_capacity);
+    if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)
+        hipLaunchKernelGGL(norm_en4_kernel<true>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
+                           (uint64_t*)nullptr, const_cast<uint8_t*>(non_ascii), out_offsets, out_text, out_capacity);
+    else
+        hipLaunchKernelGGL(norm_en_kernel<true>, dim3(norm_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets, n_docs,
+                           (uint64_t*)nullptr, const_cast<uint8_t*>(non_ascii), out_offsets, out_text, out_capacity);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }
