@@ -419,8 +419,9 @@ extern "C" int mdd_substr_check(mdd_ctx* ctx, uint64_t* n_overflow_host) {
     if (n_overflow_host) *n_overflow_host = n;
     if (n)
         return mddi::fail(MDD_ERR_INVALID,
-                          "mdd_substr_mark: %llu windows found no free table slot (tab_size too small for the windows of a "
-                          "pass: need >= 2 x windows); the marks are incomplete",
+                          "mdd_substr_mark: %llu windows found no room (table method: tab_size below 2 x the windows of a pass; "
+                          "sorted method: ent_cap below the windows of a pass, or more than 768 distinct windows in one leaf): "
+                          "the marks are incomplete -- use more passes",
                           (unsigned long long)n);
     return MDD_OK;
 }

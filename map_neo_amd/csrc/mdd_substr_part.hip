@@ -132,6 +132,8 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                            bool on = lane < nvalid && sb + L < len;
                            uint64_t key = 0;
                            if (on) {
+                               // (selecting the pass from a cheap hash of the window's first bytes BEFORE the key was tried:
+                               // no gain -- a wave computes the key as long as ONE of its 64 lanes needs it)
                                key = wkey(tv, s, L);
                                if (A.n_parts > 1 && (uint32_t)((key & 0x3FFFu) % A.n_parts) != A.part) on = false;
                            }
@@ -472,7 +474,10 @@ struct LeafArgs {
     unsigned int* n_big;       // leaves queued for bigleaf_kernel
     unsigned int* big_list;    // [BIG_LIST_CAP]
     unsigned long long* big_tab;  // [2^BIG_TAB_BITS], all-ones = empty
+    uint32_t one_round, per_round;  // LEAF_ONE_ROUND / LEAF_PER_ROUND (a testing knob lowers them: MDD_SUBSTR_LEAF_ROUND)
 };
+constexpr uint32_t LEAF_ONE_ROUND = 640;  // a leaf (slice) up to this many windows is grouped in one go (the table holds 768 distinct)
+constexpr uint32_t LEAF_PER_ROUND = 448;  // beyond: rounds of about this many
 constexpr uint32_t BIG_LEAF = 16384;      // a leaf above this many windows is sliced over all waves
 constexpr uint32_t BIG_SLICE = 4096;
 constexpr uint32_t BIG_LIST_CAP = 1u << 18;
@@ -509,7 +514,7 @@ __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 }
-constexpr int LEAF_CH = 12;     // entries per lane and chunk: 768, above nearly every leaf's size
+constexpr int LEAF_CH = 10;     // entries per lane and chunk: 640 = LEAF_ONE_ROUND, above nearly every leaf's size
 constexpr int CAND_CAP = 256;   // candidate list entries (drained when 192 are queued)
 struct LeafLds {
     unsigned long long tab[LEAF_SLOTS];
@@ -571,14 +576,16 @@ struct LeafWave {
     }
     // (a rolled loop over a rotating register array: unrolled, the body -- with the candidate drain inside -- came to
     // 150 KB of code, more than the instruction cache holds)
-    __device__ __forceinline__ void insert_chunk(unsigned long long (&e)[LEAF_CH]) {
+    // R > 1: only the entries whose tag falls into share r of R take part (the others wait for their round)
+    __device__ __forceinline__ void insert_chunk(unsigned long long (&e)[LEAF_CH], uint32_t R, uint32_t r) {
 #pragma unroll 1
         for (int k = 0; k < LEAF_CH; k++) {
-            const unsigned long long val = e[0];
+            unsigned long long val = e[0];
 #pragma unroll
             for (int j = 0; j + 1 < LEAF_CH; j++) e[j] = e[j + 1];
             e[LEAF_CH - 1] = ENT_INVALID;
-            if (__ballot(val != ENT_INVALID) == 0) break;
+            if (R > 1u && val != ENT_INVALID && ((((uint32_t)(val >> POS_BITS) & ((1u << TAG_BITS) - 1u)) * R) >> TAG_BITS) != r) val = ENT_INVALID;
+            if (__ballot(val != ENT_INVALID) == 0) continue;
             bool claimed = false, cand = false;
             uint32_t slot = leaf_home(val);
             if (val != ENT_INVALID) {
@@ -607,17 +614,31 @@ struct LeafWave {
             if (n_cand > CAND_CAP - 64) drain();
         }
     }
-    // entries [lo, hi) into the (cleared) table; `first` holds the first chunk already
-    __device__ __forceinline__ void run(uint64_t lo, uint64_t hi, unsigned long long (&first)[LEAF_CH]) {
-        insert_chunk(first);  // kept apart from the loop below so that the wait for `first` does not cover later requests
+    // share r of R of the entries [lo, hi) into the (cleared) table; `first` holds the first chunk already
+    __device__ __forceinline__ void run(uint64_t lo, uint64_t hi, unsigned long long (&first)[LEAF_CH], uint32_t R, uint32_t r) {
+        insert_chunk(first, R, r);  // kept apart from the loop below so that the wait for `first` does not cover later requests
         for (uint64_t c0 = lo + 64 * LEAF_CH; c0 < hi && distinct <= LEAF_SLOTS * 3 / 4; c0 += 64 * LEAF_CH) {
             unsigned long long more[LEAF_CH];
             load_chunk(more, c0, hi);
-            insert_chunk(more);
+            insert_chunk(more, R, r);
         }
         drain();
         // the table is filling up: chains get long and then it is full -- refuse (mdd_substr_check)
         if (distinct > LEAF_SLOTS * 3 / 4 && lane == 0) atomicAdd(A.overflow, 1ull);
+    }
+    // A range of up to BIG_LEAF entries: more than LEAF_ONE_ROUND of them are grouped in R rounds, round r taking the
+    // entries whose tag lies in share r of the tag space (equal windows have equal tags, so they meet in one round);
+    // the entries are read R times, from the L2.  after_round(): what the caller does with a round's table.
+    template <typename F>
+    __device__ __forceinline__ void group(uint64_t lo, uint64_t hi, unsigned long long (&first)[LEAF_CH], F after_round) {
+        const uint32_t n = (uint32_t)(hi - lo);
+        const uint32_t R = n > A.one_round ? (n + A.per_round - 1) / A.per_round : 1u;
+        for (uint32_t r = 0; r < R; r++) {
+            clear();
+            if (r) load_chunk(first, lo, hi);
+            run(lo, hi, first, R, r);
+            after_round();
+        }
     }
 };
 
@@ -656,9 +677,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 else atomicAdd(A.overflow, 1ull);  // (cannot happen below 2^32 entries: 2^32 / BIG_LEAF < BIG_LIST_CAP)
             }
         } else if (hi - lo >= 2) {  // a leaf with one window has no repeats
-            W.clear();
-            LEAF_T(1)
-            W.run(lo, hi, e);
+            W.group(lo, hi, e, [] {});
             LEAF_T(3)
         }
 #pragma unroll
@@ -708,15 +727,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         const uint64_t n_slices = (hi - lo + BIG_SLICE - 1) / BIG_SLICE;
         for (uint64_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
             const uint64_t slo = lo + sl * BIG_SLICE, shi = slo + BIG_SLICE < hi ? slo + BIG_SLICE : hi;
-            W.clear();
             unsigned long long e[LEAF_CH];
             W.load_chunk(e, slo, shi);
-            W.run(slo, shi, e);
-            for (int i = 0; i < LEAF_SLOTS / 64; i++) {
-                const unsigned long long v = L.tab[i * 64 + lane];
-                if (v != ENT_INVALID) big_resolve(A, v, leaf);
-            }
-            lds_sync();
+            W.group(slo, shi, e, [&] {
+                for (int i = 0; i < LEAF_SLOTS / 64; i++) {
+                    const unsigned long long v = L.tab[i * 64 + lane];
+                    if (v != ENT_INVALID) big_resolve(A, v, leaf);
+                }
+                lds_sync();
+            });
         }
     }
 }
@@ -833,6 +852,15 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     L.n_big = reinterpret_cast<unsigned int*>(counters + 6);  // zeroed with the counters above
     L.big_list = big_list;
     L.big_tab = big_tab;
+    L.one_round = LEAF_ONE_ROUND;
+    L.per_round = LEAF_PER_ROUND;
+    if (const char* knob = getenv("MDD_SUBSTR_LEAF_ROUND")) {  // testing: "one_round,per_round" below the defaults forces the multi-round path
+        unsigned a = 0, b = 0;
+        if (sscanf(knob, "%u,%u", &a, &b) == 2 && a >= 1 && a <= LEAF_ONE_ROUND && b >= 1 && b <= LEAF_PER_ROUND) {
+            L.one_round = a;
+            L.per_round = b;
+        }
+    }
     HIP_TRY(hipMemsetAsync(big_tab, 0xFF, sizeof(uint64_t) << BIG_TAB_BITS, st));
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)ctx->cus * 14), dim3(64), 0, st, L);
     hipLaunchKernelGGL(bigleaf_kernel, dim3((unsigned)ctx->cus * 14), dim3(64), 0, st, L);  // returns at once when nothing was queued

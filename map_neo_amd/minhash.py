@@ -426,7 +426,8 @@ class Engine:
         if method == "sorted":
             slack = 2048 * 28 * torch.cuda.get_device_properties(self.device).multi_processor_count + 14336
             per_win = 2 * 8 + 2                                                  # two entry arrays + the u16 side array
-            n_parts = max(1, -(-int(1.06 * n_win * per_win + slack * per_win) // max(1, table_bytes)))
+            n_parts = max(1, -(-int(1.06 * n_win * per_win + slack * per_win) // max(1, table_bytes)),
+                          -(-n_win // (1 << 33)))      # and at most 2^33 windows per pass (2^22 leaves of ~2000: 4-5 LDS rounds per leaf)
             cap = int(1.06 * n_win / n_parts) + slack + (n_win // n_parts // 16 if n_parts > 1 else 0)   # key partitions are only nearly equal
             ent_a, ent_b = self.empty(cap, torch.int64), self.empty(cap, torch.int64)
             d1 = self.empty(cap, torch.int16)

@@ -47,6 +47,7 @@ def main():
             res["docs_out"] = int(out[2].numel())
         if name == "exact_substr_dedup":
             res["key_partition_passes"] = eng.last_substr_parts
+            res["method"] = eng.last_substr_method
         if name == "paragraph_dedup":
             # size-independent property: after the stage no paragraph repeats, so a second pass changes nothing
             again = fn.__defaults__[0](out[0], out[1])
