@@ -610,12 +610,19 @@ __global__ void __launch_bounds__(256) route_count_kernel(const uint64_t* key, u
     if (threadIdx.x < (unsigned)world && loc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)loc[threadIdx.x]);
 }
 
+// Records grouped by destination rank.  A workgroup ranks its 256 records per destination in LDS, reserves one run per
+// destination (one atomic each) and -- for rows <= ROUTE_STAGE_ROWS -- stages the tuples in LDS in output order, so that
+// the global stores run through each destination's run with consecutive lanes on consecutive words (a thread storing
+// its own 13 words touches a different line with every lane: 13.8 ms per 112 M records at the C4 share).
+constexpr int ROUTE_STAGE_ROWS = 32;
 __global__ void __launch_bounds__(256) route_pack_kernel(const uint32_t* sig, int K, int bands, int rows, const uint64_t* key,
                                                          const uint64_t* meta, uint64_t n_rec, int world,
                                                          unsigned long long* cursor, uint32_t* tuples_out,
                                                          uint64_t* meta_out) {
     __shared__ unsigned int loc[64];
+    __shared__ unsigned int lstart[65];  // exclusive prefix of loc
     __shared__ unsigned long long basep[64];
+    __shared__ uint32_t stage[256 * ROUTE_STAGE_ROWS];
     if (threadIdx.x < 64) loc[threadIdx.x] = 0;
     __syncthreads();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,14 +634,44 @@ __global__ void __launch_bounds__(256) route_pack_kernel(const uint32_t* sig, in
     __syncthreads();
     if (threadIdx.x < (unsigned)world && loc[threadIdx.x])
         basep[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)loc[threadIdx.x]);
+    if (threadIdx.x == 64) {
+        unsigned int acc = 0;
+        for (int p = 0; p < world; p++) {
+            lstart[p] = acc;
+            acc += loc[p];
+        }
+        lstart[world] = acc;
+    }
     __syncthreads();
+    const uint32_t* t = nullptr;
+    uint64_t o = 0;
     if (i < n_rec) {
-        uint64_t o = basep[r] + slot;
+        o = basep[r] + slot;
         uint64_t d = i / bands;
         uint32_t j = (uint32_t)(i % bands);
-        const uint32_t* t = sig + d * (uint64_t)K + (uint64_t)j * rows;
-        for (int k = 0; k < rows; k++) tuples_out[o * rows + k] = t[k];
+        t = sig + d * (uint64_t)K + (uint64_t)j * rows;
         meta_out[o] = meta[i];
+    }
+    if (rows > ROUTE_STAGE_ROWS) {  // wide tuples (few bands): straight from the thread
+        if (i < n_rec)
+            for (int k = 0; k < rows; k++) tuples_out[o * rows + k] = t[k];
+        return;
+    }
+    if (i < n_rec) {
+        uint32_t* st = stage + (lstart[r] + slot) * (uint32_t)rows;
+        for (int k = 0; k < rows; k++) st[k] = t[k];
+    }
+    __syncthreads();
+    const uint32_t total = lstart[world] * (uint32_t)rows;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t rec = e / (uint32_t)rows;
+        int lo = 0, hi = world;  // destination of staged record `rec`: lstart[lo] <= rec < lstart[hi]
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (lstart[mid] <= rec) lo = mid;
+            else hi = mid;
+        }
+        tuples_out[(basep[lo] - lstart[lo]) * (uint64_t)rows + e] = stage[e];
     }
 }
 

@@ -588,8 +588,21 @@ struct LeafWave {
             if (__ballot(val != ENT_INVALID) == 0) continue;
             bool claimed = false, cand = false;
             uint32_t slot = leaf_home(val);
-            if (val != ENT_INVALID) {
-                for (uint32_t probe = 0; probe < LEAF_SLOTS; probe++) {
+            // four probes straight-line (a loop with two exits costs ~20 scalar mask instructions per turn, and nearly
+            // every entry is settled within four), then the general loop for the few lanes still probing
+            bool open = val != ENT_INVALID;
+#pragma unroll
+            for (int probe = 0; probe < 4; probe++) {
+                if (open) {
+                    const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
+                    claimed = cur == ENT_INVALID;
+                    cand = !claimed && (cur >> POS_BITS) == (val >> POS_BITS);
+                    open = !claimed && !cand;
+                    if (open) slot = (slot + 1) & (LEAF_SLOTS - 1);
+                }
+            }
+            if (open) {
+                for (uint32_t probe = 4; probe < LEAF_SLOTS; probe++) {
                     const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
                     if (cur == ENT_INVALID) {
                         claimed = true;
