@@ -92,3 +92,64 @@ def test_gather_docs_matches_python(engine):
     engine.sync()
     outh = out.cpu().numpy()
     assert (outh[cap:] == 0xEE).all() and outh[:cap].tobytes() == b"".join(docs)[:cap]
+
+
+def test_unaligned_buffers_take_the_byte_per_lane_kernels_and_agree(engine):
+    """the dword-per-lane count / write passes need 4-byte aligned buffers (every device allocation is); a buffer that
+    starts at an odd address takes the byte-per-lane kernels -- same results: EN normalisation, the paragraph count (the
+    stage as a whole needs 8-byte aligned text for mdd_exact_group), and the substring compaction with an unaligned mark array"""
+    import ctypes as C
+    import torch
+    from map_neo_amd import lib as _lib
+    from map_neo_amd.minhash import TEXT_PAD
+    rng = np.random.Generator(np.random.PCG64(21))
+    words = ["The", "QUICK,", "brown;", "fox", "jumps!", "over", "(the)", "lazy", "dog.", "\t", "\n", "  ", "Zebra"]
+    docs = [" ".join(rng.choice(words, int(rng.integers(0, 120)))) for _ in range(400)]
+    docs += [docs[3], docs[5], "", "x"]
+    buf, offs = pack_texts(docs)
+    text, o = engine.to_device(buf), engine.to_device(offs)
+
+    def shifted(t, k):                                  # the same bytes at (aligned address + k)
+        big = torch.zeros(t.numel() + 8, dtype=torch.uint8, device=t.device)
+        view = big[k: k + t.numel()]
+        view.copy_(t)
+        assert view.data_ptr() % 4 == k
+        return view
+
+    for k in (1, 2, 3):
+        tu = shifted(text, k)
+        a, b = engine.normalize_en(text, o), engine.normalize_en(tu, o)
+        n = int(a[1][-1].item())
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0][:n], b[0][:n]) and n > 0
+        per_a = torch.zeros(len(docs), dtype=torch.int64, device=engine.device)
+        per_b = torch.zeros_like(per_a)
+        tb_ = text.numel() - TEXT_PAD
+        _lib.check(engine.L.mdd_para_count(engine.ctx, C.c_void_p(text.data_ptr()), tb_, C.c_void_p(o.data_ptr()), len(docs),
+                                           C.c_void_p(per_a.data_ptr())))
+        _lib.check(engine.L.mdd_para_count(engine.ctx, C.c_void_p(tu.data_ptr()), tb_, C.c_void_p(o.data_ptr()), len(docs),
+                                           C.c_void_p(per_b.data_ptr())))
+        assert torch.equal(per_a, per_b) and int(per_a.sum().item()) > len(docs)
+    # substring compaction: marks from the table method, then count + write with the mark array at an odd address
+    nd = len(docs)
+    tb = text.numel() - TEXT_PAD
+    p = lambda t: C.c_void_p(t.data_ptr())
+    dup = torch.zeros(tb, dtype=torch.uint8, device=engine.device)
+    table = torch.empty(4 * tb + 16, dtype=torch.int64, device=engine.device)
+    _lib.check(engine.L.mdd_substr_mark(engine.ctx, p(text), tb, p(o), nd, 20, 0, 1, p(table), table.numel(), p(dup)))
+    _lib.check(engine.L.mdd_substr_check(engine.ctx, None))
+    assert int(dup.sum().item()) > 0
+    outs = []
+    for d in (dup, shifted(dup, 1), shifted(dup, 3)):
+        kb = torch.zeros(nd, dtype=torch.int64, device=engine.device)
+        kc = torch.zeros(nd, dtype=torch.int64, device=engine.device)
+        _lib.check(engine.L.mdd_substr_count(engine.ctx, p(text), tb, p(o), nd, 20, p(d), p(kb), p(kc)))
+        oo = torch.zeros(nd + 1, dtype=torch.int64, device=engine.device)
+        torch.cumsum(kb, 0, out=oo[1:])
+        total = int(oo[-1].item())
+        out = torch.zeros(total + TEXT_PAD, dtype=torch.uint8, device=engine.device)
+        keep = torch.ones(nd, dtype=torch.uint8, device=engine.device)
+        _lib.check(engine.L.mdd_substr_write(engine.ctx, p(text), tb, p(o), nd, 20, p(d), p(keep), p(oo), p(out), total))
+        outs.append((kb.clone(), kc.clone(), out[:total].clone()))
+    for x in outs[1:]:
+        assert all(torch.equal(u, v) for u, v in zip(outs[0], x))
+    assert 0 < outs[0][2].numel() < tb
