@@ -405,7 +405,7 @@ class Engine:
                      table_bytes: Optional[int] = None, method: str = "auto"):
         """Exact substring dedup of a packed corpus (SUB:34-95).  Returns (out_text uint8 [padded],
         out_offsets int64 [n_kept+1], kept document indices int64).  The window table (16 bytes per window)
-        is limited to table_bytes (default: 40 % of the free HBM); beyond that the windows are processed in
+        is limited to table_bytes (default: 70 % of the free HBM); beyond that the windows are processed in
         several passes partitioned by content key."""
         n = offsets.numel() - 1
         if n <= 0:
@@ -416,7 +416,10 @@ class Engine:
         n_win = int(torch.clamp(lens - window, min=0).sum().item())        # code points <= bytes: an upper bound
         dup = self.empty(max(1, text_bytes), torch.uint8)
         if table_bytes is None:
-            table_bytes = int(torch.cuda.mem_get_info(self.device)[0] * 0.4)
+            # the workspace is released before the outputs are allocated (and the caching allocator hands its blocks on), so most
+            # of the free memory can go to it: fewer passes, and every pass re-walks all windows
+            free = torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+            table_bytes = int(free * 0.7)              # (blocks the caching allocator holds but nobody uses are free too)
         # "sorted": partition the windows into leaves and group them in LDS (mdd_substr_mark_sorted) -- pays once the
         # table of the "table" method (one random atomic per window) is far beyond the caches; "table": mdd_substr_mark
         if method == "auto":

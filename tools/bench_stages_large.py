@@ -48,6 +48,16 @@ def main():
         if name == "exact_substr_dedup":
             res["key_partition_passes"] = eng.last_substr_parts
             res["method"] = eng.last_substr_method
+            # the first call pays for mapping ~150 GB of workspace (hipMalloc through torch's caching allocator); a pipeline
+            # that runs the stage batch after batch keeps the blocks: time it again
+            del out
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            res["s_warm"] = time.perf_counter() - t0
+            res["docs_per_s_warm"] = a.docs / res["s_warm"]
+            res["key_partition_passes_warm"] = eng.last_substr_parts
         if name == "paragraph_dedup":
             # size-independent property: after the stage no paragraph repeats, so a second pass changes nothing
             again = fn.__defaults__[0](out[0], out[1])
