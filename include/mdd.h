@@ -118,7 +118,7 @@ int mdd_signatures_noalloc(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
  *   text_host   HOST pointer, pinned (hipHostMalloc / hipHostRegister / torch pin_memory)
  *   text_dev    device buffer, 256-byte aligned, text_bytes + MDD_TEXT_PAD capacity; holds the text afterwards
  *   offsets     DEVICE, n_docs+1 (copy them first, on the context's stream)
- *   chunk_bytes copy granularity (0 = 64 MiB; a multiple of 256, >= 1 MiB; the first chunks are smaller)
+ *   chunk_bytes copy granularity (0 = 32 MiB; a multiple of 256, >= 1 MiB)
  * Asynchronous.  The kernel cannot wait forever: a wave that has waited 4 s for its text sets a status word and
  * every wave leaves; the next mdd_ctx_sync then returns MDD_ERR_HIP.  The first call on a context allocates a
  * small pinned table and three events (set-up); later calls allocate nothing. */
