@@ -515,7 +515,8 @@ __device__ __forceinline__ void lds_sync() {
     asm volatile("" ::: "memory");
 }
 constexpr int LEAF_CH = 10;     // entries per lane and chunk: 640 = LEAF_ONE_ROUND, above nearly every leaf's size
-constexpr int CAND_CAP = 256;   // candidate list entries (drained when 192 are queued)
+constexpr int LEAF_ILP = 1;     // entries a lane inserts side by side (2 measured: 29.3 vs 29.5 ms, no gain)
+constexpr int CAND_CAP = 256;   // candidate list entries (drained when a step could overflow it)
 struct LeafLds {
     unsigned long long tab[LEAF_SLOTS];
     unsigned long long cval[CAND_CAP];
@@ -578,53 +579,75 @@ struct LeafWave {
     // 150 KB of code, more than the instruction cache holds)
     // R > 1: only the entries whose tag falls into share r of R take part (the others wait for their round)
     __device__ __forceinline__ void insert_chunk(unsigned long long (&e)[LEAF_CH], uint32_t R, uint32_t r) {
+        static_assert(LEAF_CH % LEAF_ILP == 0, "whole groups of entries per step");
 #pragma unroll 1
-        for (int k = 0; k < LEAF_CH; k++) {
-            unsigned long long val = e[0];
+        for (int k = 0; k < LEAF_CH; k += LEAF_ILP) {
+            // LEAF_ILP entries per lane and step: what a step costs is the round trip of an LDS atomic with return (hundreds
+            // of cycles) times the length of the dependent probe chain; independent chains overlap their round trips
+            unsigned long long val[LEAF_ILP];
 #pragma unroll
-            for (int j = 0; j + 1 < LEAF_CH; j++) e[j] = e[j + 1];
-            e[LEAF_CH - 1] = ENT_INVALID;
-            if (R > 1u && val != ENT_INVALID && ((((uint32_t)(val >> POS_BITS) & ((1u << TAG_BITS) - 1u)) * R) >> TAG_BITS) != r) val = ENT_INVALID;
-            if (__ballot(val != ENT_INVALID) == 0) continue;
-            bool claimed = false, cand = false;
-            uint32_t slot = leaf_home(val);
+            for (int u = 0; u < LEAF_ILP; u++) val[u] = e[u];
+#pragma unroll
+            for (int j = 0; j + LEAF_ILP < LEAF_CH; j++) e[j] = e[j + LEAF_ILP];
+#pragma unroll
+            for (int u = 0; u < LEAF_ILP; u++) e[LEAF_CH - 1 - u] = ENT_INVALID;
+            bool open[LEAF_ILP], claimed[LEAF_ILP], cand[LEAF_ILP];
+            uint32_t slot[LEAF_ILP];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < LEAF_ILP; u++) {
+                if (R > 1u && val[u] != ENT_INVALID && ((((uint32_t)(val[u] >> POS_BITS) & ((1u << TAG_BITS) - 1u)) * R) >> TAG_BITS) != r)
+                    val[u] = ENT_INVALID;
+                open[u] = val[u] != ENT_INVALID;
+                claimed[u] = cand[u] = false;
+                slot[u] = leaf_home(val[u]);
+                any = any || open[u];
+            }
+            if (__ballot(any) == 0) continue;
             // four probes straight-line (a loop with two exits costs ~20 scalar mask instructions per turn, and nearly
             // every entry is settled within four), then the general loop for the few lanes still probing
-            bool open = val != ENT_INVALID;
 #pragma unroll
             for (int probe = 0; probe < 4; probe++) {
-                if (open) {
-                    const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
-                    claimed = cur == ENT_INVALID;
-                    cand = !claimed && (cur >> POS_BITS) == (val >> POS_BITS);
-                    open = !claimed && !cand;
-                    if (open) slot = (slot + 1) & (LEAF_SLOTS - 1);
-                }
-            }
-            if (open) {
-                for (uint32_t probe = 4; probe < LEAF_SLOTS; probe++) {
-                    const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
-                    if (cur == ENT_INVALID) {
-                        claimed = true;
-                        break;
+                unsigned long long cur[LEAF_ILP];
+#pragma unroll
+                for (int u = 0; u < LEAF_ILP; u++)
+                    if (open[u]) cur[u] = atomicCAS(&L.tab[slot[u]], ENT_INVALID, val[u]);
+#pragma unroll
+                for (int u = 0; u < LEAF_ILP; u++)
+                    if (open[u]) {
+                        claimed[u] = cur[u] == ENT_INVALID;
+                        cand[u] = !claimed[u] && (cur[u] >> POS_BITS) == (val[u] >> POS_BITS);
+                        open[u] = !claimed[u] && !cand[u];
+                        if (open[u]) slot[u] = (slot[u] + 1) & (LEAF_SLOTS - 1);
                     }
-                    if ((cur >> POS_BITS) == (val >> POS_BITS)) {
-                        cand = true;
-                        break;
+            }
+#pragma unroll
+            for (int u = 0; u < LEAF_ILP; u++) {
+                if (open[u]) {
+                    for (uint32_t probe = 4; probe < LEAF_SLOTS; probe++) {
+                        const unsigned long long c = atomicCAS(&L.tab[slot[u]], ENT_INVALID, val[u]);
+                        if (c == ENT_INVALID) {
+                            claimed[u] = true;
+                            break;
+                        }
+                        if ((c >> POS_BITS) == (val[u] >> POS_BITS)) {
+                            cand[u] = true;
+                            break;
+                        }
+                        slot[u] = (slot[u] + 1) & (LEAF_SLOTS - 1);
                     }
-                    slot = (slot + 1) & (LEAF_SLOTS - 1);
+                    if (!claimed[u] && !cand[u]) atomicAdd(A.overflow, 1ull);  // table full
                 }
-                if (!claimed && !cand) atomicAdd(A.overflow, 1ull);  // table full
+                distinct += (uint32_t)__popcll(__ballot(claimed[u]));
+                const uint64_t cb = __ballot(cand[u]);
+                if (cand[u]) {
+                    const uint32_t at = n_cand + below(cb);
+                    L.cval[at] = val[u];
+                    L.cslot[at] = (uint16_t)slot[u];
+                }
+                n_cand += (uint32_t)__popcll(cb);
             }
-            distinct += (uint32_t)__popcll(__ballot(claimed));
-            const uint64_t cb = __ballot(cand);
-            if (cand) {
-                const uint32_t at = n_cand + below(cb);
-                L.cval[at] = val;
-                L.cslot[at] = (uint16_t)slot;
-            }
-            n_cand += (uint32_t)__popcll(cb);
-            if (n_cand > CAND_CAP - 64) drain();
+            if (n_cand > CAND_CAP - 64 * LEAF_ILP) drain();
         }
     }
     // share r of R of the entries [lo, hi) into the (cleared) table; `first` holds the first chunk already
