@@ -134,7 +134,9 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                            if (on) {
                                // (selecting the pass from a cheap hash of the window's first bytes BEFORE the key was tried:
                                // no gain -- a wave computes the key as long as ONE of its 64 lanes needs it)
-                               key = wkey(tv, s, L);
+                               // (pure-ASCII segment: every window is A.window bytes long -- a wave-uniform length lets the
+                               // compiler do the loop control and the tail mask of the key on the scalar unit)
+                               key = ascii ? wkey(tv, s, A.window) : wkey(tv, s, L);
                                if (A.n_parts > 1 && (uint32_t)((key & 0x3FFFu) % A.n_parts) != A.part) on = false;
                            }
                            const uint64_t bal = __ballot(on);
