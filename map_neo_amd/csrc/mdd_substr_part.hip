@@ -10,9 +10,10 @@
 //   count2 / scatter<2>   the same inside every partition on d2 = key bits 52..42  ->  2^22 leaves of ~500 windows
 //   leaf      one wave per leaf: an LDS table of 8-byte entries (tag | lowest position); a tag match is confirmed by
 //             COMPARING THE BYTES of the two windows (so the result is exact), the later window of a matching pair is
-//             marked.  Leaves of any size work (boilerplate puts millions of identical windows into one leaf: they share
-//             one LDS slot); more than LEAF_SLOTS * 3/4 DISTINCT windows in one leaf (hash adversary) raise the overflow
-//             count that mdd_substr_check reports.
+//             marked.  Leaves of any size work: above 640 windows a leaf is grouped in rounds over shares of the tag space,
+//             above 16384 (boilerplate puts millions of identical windows into one leaf) it is sliced over all waves and
+//             the slices meet in a small global table (bigleaf_kernel); more than LEAF_SLOTS * 3/4 DISTINCT windows in one
+//             round (hash adversary) raise the overflow count that mdd_substr_check reports.
 // Equal 64-bit keys land in the same leaf, so every pair of identical windows meets in one LDS table.
 #include "mdd_shingle.h"
 
@@ -255,7 +256,7 @@ static int exclusive_scan(hipStream_t st, const unsigned int* cnt, uint64_t n, u
 // non-empty bin and tile) and written out in sorted order: consecutive lanes hold consecutive entries of a bin's run and
 // a store instruction touches few lines.  What then bounds a level is the number of RUNS: a run is a random DRAM access,
 // and the chip sustains ~17.5 G of those per second (the same figure as its random atomics).
-//   level 1: 2048 bins, tiles of 12288 -> runs of 6 entries scattered over the whole entry array (20 ms on C2)
+//   level 1: 2048 bins, tiles of 12288 -> runs of 6 entries scattered over the whole entry array (17 ms on C2)
 //   level 2: 2048 bins, tiles of 16384 -> runs of 8 entries, but inside one partition (8 MB), where the XCD's L2 merges
 //            them into full lines (9 ms): tiles never straddle a partition (tile_off = running sum of ceil(size_p / 16384)) and
 //            workgroup b takes tile (b % 8) * ceil(T / 8) + b / 8, so the workgroups of one XCD (b % 8) walk through one
