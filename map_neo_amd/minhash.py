@@ -419,7 +419,7 @@ class Engine:
             # the workspace is released before the outputs are allocated (and the caching allocator hands its blocks on), so most
             # of the free memory can go to it: fewer passes, and every pass re-walks all windows
             free = torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-            table_bytes = int(free * 0.7)              # (blocks the caching allocator holds but nobody uses are free too)
+            table_bytes = int(free * float(os.environ.get("MDD_SUBSTR_MEM_FRAC", "0.7")))   # (allocator-cached blocks are free too)
         # "sorted": partition the windows into leaves and group them in LDS (mdd_substr_mark_sorted) -- pays once the
         # table of the "table" method (one random atomic per window) is far beyond the caches; "table": mdd_substr_mark
         if method == "auto":
