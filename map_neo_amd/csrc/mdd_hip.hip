@@ -194,11 +194,22 @@ __device__ __noinline__ uint32_t hash_multi(const uint32_t* docw, uint32_t p, ui
     return __builtin_bswap32(st[0]);
 }
 
-// wave-uniform dispatch on the longest shingle of the round
+// wave-uniform dispatch on the shingle lengths of the round (every lane holds a valid shingle: lanes past the round's
+// end repeat lane 0's).  Lmax != 0: all lanes have that length (pure-ASCII document).  Otherwise the tier comes from
+// ballots (one compare each; a wave maximum costs six cross-lane steps), most likely cases first: all shingles 39 bytes
+// (13 three-byte code points: CJK text) -> the padding folds at compile time like the ASCII case; <= 15; <= 39; <= 55.
 __device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint32_t p, uint32_t L, uint32_t Lmax, bool fixed13) {
     if (fixed13) {
         MDD_REGION("sha_a13", PR_SHA_A13);
         return hash_single<4, 13>(tv, p, L);
+    }
+    if (Lmax == 0u) {
+        if (__ballot(L != 39u) == 0) {
+            MDD_REGION("sha10", PR_SHA10);
+            return hash_single<10, 39>(tv, p, L);
+        }
+        if (__ballot(L > 39u) == 0) Lmax = __ballot(L > 15u) ? 39u : 15u;
+        else Lmax = __ballot(L > 55u) ? 56u : 55u;  // (a 12-word tier for <= 47 bytes was tried: no gain for word 5-grams)
     }
     if (Lmax <= 15u) {
         MDD_REGION("sha4", PR_SHA4);
@@ -401,7 +412,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #ifdef MDD_DBG_NOSHA   // development ablation only (tools/sig_bench.hip); never defined in the library build
                 uint32_t h = s * 2654435761u + L;
 #else
-                uint32_t Lmax = ascii ? width : uni(wave_max(L));
+                uint32_t Lmax = ascii ? width : 0u;  // 0: lengths differ between lanes, hash_any looks at them
                 uint32_t h = hash_any(tv, s, L, Lmax, ascii && width == 13u);
 #endif
 
