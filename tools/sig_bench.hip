@@ -7,6 +7,8 @@
 // Built with -DMDD_PATHCOUNT (build/sig_bench_count) the kernel also counts how often each MDD_REGION is entered
 // (one launch) and the tool prints them as JSON: the dynamic side of tools/issue_model.py.
 #include "../map_neo_amd/csrc/mdd_hip.hip"
+// mdd_ctx_destroy releases the context's communicator; this single-file tool has none and does not link mdd_comm.hip
+extern "C" int mdd_comm_destroy(mdd_ctx*) { return 0; }
 
 #include <cmath>
 #include <cstdlib>

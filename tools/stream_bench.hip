@@ -3,6 +3,8 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o build/stream_bench tools/stream_bench.hip
 //   ./build/stream_bench [n_docs] [chunk_mib]
 #include "../map_neo_amd/csrc/mdd_hip.hip"
+// mdd_ctx_destroy releases the context's communicator; this single-file tool has none and does not link mdd_comm.hip
+extern "C" int mdd_comm_destroy(mdd_ctx*) { return 0; }
 
 #include <chrono>
 #include <cmath>
