@@ -253,6 +253,7 @@ struct SigArgs {
     // documents longer than seg_bytes are cut into segments of shingle START offsets; segment 0
     // belongs to the document's own wave, segments >= 1 are listed in items[] (doc << 24 | seg)
     uint32_t seg_bytes;
+    uint32_t batch_shift, max_batch;  // a claim on the work counter takes (items left) >> batch_shift items, clamped to [1, max_batch]
     uint32_t filter_from;  // shingles of a work item permuted in full before the filter starts (0xFFFFFFFF: never)
     const uint64_t* items;
     const uint64_t* n_items;
@@ -349,25 +350,37 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         }
     }
 
-    // ---- persistent wave: work items (documents, then queued segments of long documents) are
-    // pulled from one device counter; the next index is fetched before the current item is
-    // processed so the atomic's latency hides behind ~10^5 cycles of hashing.  Every wave
-    // leaves the loop once the counter passes `total`; no workgroup barrier is used anywhere.
+    // ---- persistent wave: work items (documents, then queued segments of long documents) are claimed from one
+    // device counter in BATCHES of consecutive items.  Same-address atomics retire at ~11 ns each on this chip
+    //  and a wave waits for its claim, so one claim per document caps the kernel at ~90 M documents/s
+    // -- that, not the hashing, bound short-shingle-count inputs (1 M word-5-gram documents: 12.3 ms = 1 M x 11 ns + ...).
+    // Guided self-scheduling: a claim takes (items left) >> batch_shift items, clamped to [1, max_batch], i.e.
+    // larger batches while there is plenty of work and single items at the end, so the waves still finish together.
+    // max_batch comes from the host (signatures_impl): just large enough to keep the claims well below that cap.
+    // Every wave leaves the loop once the counter passes `total`; no workgroup barrier is used anywhere.
+    const uint32_t MAX_BATCH = STREAM || A.max_batch == 0u ? 1u : A.max_batch;  // streamed input arrives in document order: keep the claims in that order
     uint64_t total = 1;
     if (!DUMP) {
         uint64_t extra = *A.n_items;  // final: seg_plan_kernel ran before this kernel on the stream
         total = A.n_docs + (extra < A.max_items ? extra : A.max_items);
     }
-    auto fetch = [&]() -> uint64_t {
+    auto fetch = [&](uint32_t n) -> uint64_t {
         unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(A.work_counter, 1ull);
+        if (lane == 0) v = atomicAdd(A.work_counter, (unsigned long long)n);
         uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
         return ((uint64_t)hi << 32) | lo;
     };
-    uint64_t item = DUMP ? 0 : fetch();
-    while (item < total) {
+    uint64_t item = 0, batch_end = DUMP ? 1 : 0;
+    for (;; item++) {
+        if (item >= batch_end) {  // claim the next batch (never in DUMP mode, which returns after its one document)
+            // `item` is the end of this wave's previous batch: a lower bound of the counter
+            const uint64_t want = (total > item ? total - item : 0) >> A.batch_shift;
+            const uint32_t n = want < 1u ? 1u : (want > MAX_BATCH ? MAX_BATCH : (uint32_t)want);
+            item = fetch(n);
+            if (item >= total) break;
+            batch_end = item + n < total ? item + n : total;
+        }
         MDD_REGION("item", PR_ITEM);
-        uint64_t next_item = DUMP ? total : fetch();
         uint64_t d = item;
         uint32_t seg = 0;
         if (!DUMP && d >= A.n_docs) {
@@ -575,8 +588,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 else if (n_sh_total) atomicMin(&A.sig[d * (uint64_t)A.K + pi], m[q]);  // row preset by seg_plan_kernel
             }
         }
-        item = next_item;
-    }  // while (item < total)
+    }  // for (;; item++)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1207,6 +1219,19 @@ static int signatures_impl(const char* fn, mdd_ctx* ctx, const uint8_t* text, ui
     // counter exhausted and leave at once
     uint64_t waves = (uint64_t)ctx->cus * 4 * 8;
     if (waves > n_docs + max_items) waves = n_docs + max_items;
+    // batch size of a claim: (items left) / (4 x the waves the chip holds at once), see sig_kernel
+    uint64_t resident = (uint64_t)ctx->cus * 4 * MDD_WPE;
+    if (resident > waves) resident = waves;
+    while ((1ull << A.batch_shift) < resident * 4) A.batch_shift++;
+    // Measured on 1 M documents of ~2.2 KB (tools/ab_word.sh): word 5-grams 12.27 ms with single claims, 11.03 with <= 4,
+    // 11.11 with <= 8, 11.25 with <= 16; ASCII char 13-grams 54.25 / 54.5 / 54.8 / 55.6 ms -- larger batches cost a little
+    // (the documents in flight spread over more memory), so take the smallest batch that keeps the claims under ~1/4 of
+    // the counter's ~90 M/s at the rate the unit can reach (word ~180 GB/s, char <= ~100 GB/s of text).
+    {
+        const uint64_t avg = text_bytes / n_docs + 1, rate = unit == MDD_UNIT_CHAR ? 4096 : 8192;
+        const uint64_t mb = (rate + avg - 1) / avg;
+        A.max_batch = (uint32_t)(mb < 1 ? 1 : (mb > 8 ? 8 : mb));
+    }
     return launch_sig<false>(ctx, A, grid_for(waves, WAVES));
 }
 

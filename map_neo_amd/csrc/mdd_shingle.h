@@ -93,6 +93,7 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
     bool skip_end = unit != MDD_UNIT_CHAR && seg_beg > 0 && seg_beg < len && text[beg + seg_beg - 1] != 0x20 &&
                     text[beg + seg_beg] != 0x20;
     const uint32_t look = unit == MDD_UNIT_CHAR ? width : width - 1;
+    uint32_t open_w = skip_end ? 1u : 0u;  // word unit: a token spans the first byte of the next scan window (ends come one short)
     uint32_t n_done = 0;
     uint32_t ascii_total = 0;  // shingles of this segment when boundaries are implicit
     if (ascii && len >= width) {
@@ -106,16 +107,18 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
     uint32_t pfa_lo = 0, pfa_hi = 0, pfb_lo = 0, pfb_hi = 0;
     auto window_load = [&](uint32_t wpos, uint32_t& lo, uint32_t& hi) {
         uint32_t p0 = wpos + 4u * lane;
-        bool in = wpos < len && p0 < len;  // reads stay within 8 bytes of the document's end
-        uint32_t i = (boff + p0) >> 2;
-        lo = in ? tv.docw[i] : 0u;
-        hi = in ? tv.docw[i + 1] : 0u;
+        // bytes at or after len are masked out by the scan (inm), so a lane past the end may load anything that is
+        // mapped: it re-reads the document's first dwords.  No branch and no select on the loaded value: the load
+        // then writes the prefetch registers directly and is only waited for where the scan consumes it.
+        uint32_t i = p0 < len ? (boff + p0) >> 2 : 0u;  // reads stay within 8 bytes of the document's end
+        lo = tv.docw[i];
+        hi = tv.docw[i + 1];
     };
-    bool carry_sp = true;  // word unit: the byte before the scan window is a space (or the document starts)
+    uint32_t carry_sp = 0x80000000u;  // word unit, bit 31: the byte before the scan window is a space (or the document starts)
     if (!ascii) {
         window_load(pos, pfa_lo, pfa_hi);
         window_load(pos + 256u, pfb_lo, pfb_hi);
-        if (unit != MDD_UNIT_CHAR && pos > 0 && pos <= len) carry_sp = text[beg + pos - 1] == 0x20;
+        if (unit != MDD_UNIT_CHAR && pos > 0 && pos <= len) carry_sp = text[beg + pos - 1] == 0x20 ? 0x80000000u : 0u;
     }
 
     for (;;) {
@@ -139,59 +142,67 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
                 // window = doc-relative bytes [pos, pos+256); lane handles 4 of them
                 uint32_t p0 = pos + 4u * lane;
                 uint32_t w4 = __builtin_amdgcn_alignbyte(pfa_hi, pfa_lo, boff);  // bytes p0 .. p0+3
-                uint32_t nb = (pfa_hi >> (8u * boff)) & 0xFFu;                     // byte p0+4
+                const uint32_t pfn_hi = pfa_hi;  // byte p0+4 is its byte boff
                 pfa_lo = pfb_lo;
                 pfa_hi = pfb_hi;
+                asm volatile("" : "+v"(pfa_lo), "+v"(pfa_hi));  // rotate NOW, so that the load below can write pfb itself
                 window_load(pos + 512u, pfb_lo, pfb_hi);
                 uint32_t nval = p0 < len ? (len - p0 < 4u ? len - p0 : 4u) : 0u;
-                uint32_t fs = 0, fe = 0;
+                // Flags live in bit 7 of byte k (SWAR over the lane's dword): inm = byte p0+k lies inside the document
+                const uint32_t inm = nval >= 4u ? 0x80808080u : 0x00808080u >> (8u * (3u - nval));
+                uint32_t fs, fe = 0;  // byte k starts / ends a unit
+                uint32_t open_l = 0, open_next = 0;
                 if (unit == MDD_UNIT_CHAR) {
+                    fs = inm & (~w4 | (w4 << 1));  // not a continuation byte 10xxxxxx: bit 7 clear or bit 6 set
+                } else {
+                    const uint32_t x = w4 ^ 0x20202020u;
+                    const uint32_t nsp = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & inm;  // byte is inside and no space
+                    const uint32_t sp = ~nsp & 0x80808080u;                            // a space, or past the end
+                    // the neighbours' flags come over DPP wave shifts (lane l reads lane l -/+ 1; the end lanes keep
+                    // `old`): lane 0's left neighbour is the carry of the previous window, lane 63's right neighbour
+                    // is byte pos + 256, taken from lane 63's second dword
+                    const uint32_t nb63 = (__builtin_amdgcn_readlane(pfn_hi, 63) >> (8u * boff)) & 0xFFu;
+                    const uint32_t right = (pos + 256u >= len || nb63 == 0x20u) ? 0x80u : 0u;
+                    const uint32_t sp_prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_sp, (int)sp, 0x138, 0xf, 0xf, false);
+                    const uint32_t sp_next = (uint32_t)__builtin_amdgcn_update_dpp((int)right, (int)sp, 0x130, 0xf, 0xf, false);
+                    carry_sp = __builtin_amdgcn_readlane(sp, 63);
+                    fs = nsp & __builtin_amdgcn_alignbit(sp, sp_prev, 24);  // byte k-1 is a space: (sp << 8) | (sp_prev >> 24)
+                    fe = nsp & __builtin_amdgcn_alignbit(sp_next, sp, 8);   // byte k+1 is a space: (sp >> 8) | (sp_next << 24)
+                    open_l = ((nsp ^ fs) >> 7) & 1u;  // the lane's first byte continues a word begun in a lower lane
+                    open_next = ((carry_sp >> 31) == 0u && right == 0u) ? 1u : 0u;  // a word runs on into the next window
+                }
+                // ranks in byte order from the bit planes of the lanes' counts: a dword holds at most 4 code-point
+                // starts (3 planes), and at most 2 word starts and 2 word ends (2 planes each)
+                const uint32_t cs = (uint32_t)__popc(fs);
+                const uint64_t s0 = __ballot(cs & 1u), s1 = __ballot(cs & 2u);
+                uint32_t rank_s = below(s0) + 2u * below(s1);
+                uint32_t tot_s = (uint32_t)__popcll(s0) + 2u * (uint32_t)__popcll(s1), tot_e = 0;
+                if (unit == MDD_UNIT_CHAR) {
+                    const uint64_t s2 = __ballot(cs & 4u);
+                    rank_s += 4u * below(s2);
+                    tot_s += 4u * (uint32_t)__popcll(s2);
+                    uint32_t rs = n_entS + rank_s;
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if ((uint32_t)k < nval && ((w4 >> (8 * k)) & 0xC0u) != 0x80u) fs |= 1u << k;
+                        if (fs & (0x80u << (8 * k))) lds.ringS[(rs++) & (RING - 1)] = p0 + k;
                 } else {
-                    bool spk[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) spk[k] = (uint32_t)k < nval ? ((w4 >> (8 * k)) & 0xFFu) == 0x20u : true;
-                    bool next4 = p0 + 4u < len ? nb == 0x20u : true;
-                    uint32_t last = spk[3] ? 1u : 0u;
-                    uint32_t up = (uint32_t)__shfl_up((int)last, 1, 64);
-                    bool prev_sp = lane == 0 ? carry_sp : up != 0u;
-                    carry_sp = __builtin_amdgcn_readlane(last, 63) != 0u;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        bool in = (uint32_t)k < nval;
-                        bool sp = spk[k];
-                        bool next_sp = k < 3 ? spk[k + 1] : next4;
-                        if (in && !sp && prev_sp) fs |= 1u << k;
-                        if (in && !sp && next_sp) fe |= 1u << k;
-                        prev_sp = sp;
+                    // Starts and ends alternate, so the ends below a lane follow from the starts below it, the word
+                    // that spans the lane's first byte and the word that spans the window's first byte (open_w).
+                    // (starts below byte p) - (ends below byte p) = [a word spans the boundary before byte p], so:
+                    const uint32_t rank_e = rank_s - open_l + open_w;
+                    tot_e = tot_s - open_next + open_w;
+                    open_w = open_next;
+                    // first / last flagged byte: bit 8k+7 -> k
+                    if (fs) {
+                        const uint32_t rs = n_entS + rank_s;
+                        lds.ringS[rs & (RING - 1)] = p0 + ((uint32_t)__builtin_ctz(fs) >> 3);
+                        if (cs == 2u) lds.ringS[(rs + 1u) & (RING - 1)] = p0 + ((31u - (uint32_t)__builtin_clz(fs)) >> 3);
                     }
-                }
-                // ranks in byte order: 4 ballots (one per byte slot)
-                uint32_t rank_s = 0, tot_s = 0, rank_e = 0, tot_e = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint64_t bs = __ballot((fs >> k) & 1u);
-                    rank_s += below(bs);
-                    tot_s += (uint32_t)__popcll(bs);
-                    if (unit != MDD_UNIT_CHAR) {
-                        uint64_t be = __ballot((fe >> k) & 1u);
-                        rank_e += below(be);
-                        tot_e += (uint32_t)__popcll(be);
-                    }
-                }
-                uint32_t rs = n_entS + rank_s, re = rank_e;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if ((fs >> k) & 1u) lds.ringS[(rs++) & (RING - 1)] = p0 + k;
-                    if (unit != MDD_UNIT_CHAR && ((fe >> k) & 1u)) {
-                        uint32_t idx = re++;
-                        if (skip_end) {
-                            if (idx == 0) continue;
-                            idx -= 1;
-                        }
-                        lds.ringE[(n_entE + idx) & (RING - 1)] = p0 + k + 1;
+                    if (fe) {  // skip_end drops the window's (= the segment's) very first end
+                        const uint32_t sk = skip_end ? 1u : 0u;
+                        const uint32_t re = n_entE + rank_e - sk;
+                        if (!(sk && rank_e == 0u)) lds.ringE[re & (RING - 1)] = p0 + ((uint32_t)__builtin_ctz(fe) >> 3) + 1u;
+                        if (fe & (fe - 1u)) lds.ringE[(re + 1u) & (RING - 1)] = p0 + ((31u - (uint32_t)__builtin_clz(fe)) >> 3) + 1u;
                     }
                 }
                 n_entS += tot_s;
@@ -232,6 +243,10 @@ __device__ __forceinline__ uint32_t for_each_round(WaveLds& lds, const uint8_t* 
                     }
                 }
             }
+            // the ring only ever holds offsets sb < eb <= len; a clamp keeps every text read inside the document even
+            // if that invariant were broken (two VALU per round of 64 shingles)
+            sb = sb < len ? sb : len;
+            eb = eb < sb ? sb : (eb < len ? eb : len);
             s = boff + sb;
             L = eb - sb;
         }

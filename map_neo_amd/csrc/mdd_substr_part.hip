@@ -84,6 +84,7 @@ struct EmitArgs {
     unsigned int* hist1;        // [BINS1]
     unsigned long long* overflow;
     uint32_t part, n_parts;
+    uint32_t batch_shift;  // a claim on the work counter takes (items left) >> batch_shift items, clamped to [1, 16]
 };
 
 // persistent waves pulling documents (then queued segments of long documents) from one counter, four waves per workgroup
@@ -99,16 +100,24 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
     const uint32_t* tw = reinterpret_cast<const uint32_t*>(A.text);
     const uint64_t extra = *A.n_items;
     const uint64_t total = A.n_docs + (extra < A.max_items ? extra : A.max_items);
-    auto fetch = [&]() -> uint64_t {
+    // work items are claimed in batches (guided self-scheduling as in sig_kernel, mdd_hip.hip: same-address atomics retire
+    // at ~11 ns each and the wave waits for its claim, so one claim per document would cap this kernel at ~90 M documents/s)
+    auto fetch = [&](uint32_t n) -> uint64_t {
         unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(A.work_counter, 1ull);
+        if (lane == 0) v = atomicAdd(A.work_counter, (unsigned long long)n);
         uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
         return ((uint64_t)hi << 32) | lo;
     };
     uint64_t chunk_pos = 0, chunk_end = 0;  // this wave's current chunk of the entry array (wave-uniform)
-    uint64_t item = fetch();
-    while (item < total) {
-        uint64_t next_item = fetch();
+    uint64_t item = 0, batch_end = 0;
+    for (;; item++) {
+        if (item >= batch_end) {  // `item` = end of this wave's previous batch: a lower bound of the counter
+            const uint64_t want = (total > item ? total - item : 0) >> A.batch_shift;
+            const uint32_t n = want < 1u ? 1u : (want > 16u ? 16u : (uint32_t)want);
+            item = fetch(n);
+            if (item >= total) break;
+            batch_end = item + n < total ? item + n : total;
+        }
         uint64_t d = item;
         uint32_t seg = 0;
         if (d >= A.n_docs) {
@@ -166,7 +175,6 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                            }
                            chunk_pos += cnt;
                        });
-        item = next_item;
     }
     for (uint64_t i = chunk_pos + lane; i < chunk_end && i < A.ent_cap; i += 64) {  // void what is left of the last chunk
         A.ent[i] = ENT_INVALID;
@@ -854,6 +862,7 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
                        ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, (uint32_t*)nullptr, 0);
     HIP_TRY(hipGetLastError());
     uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
+    while ((1ull << E.batch_shift) < w * 4) E.batch_shift++;
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((w + EMIT_WAVES - 1) / EMIT_WAVES)), dim3(64 * EMIT_WAVES), 0, st, E);
     HIP_TRY(hipGetLastError());
     // ---- level 1
