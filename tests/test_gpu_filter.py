@@ -142,3 +142,28 @@ def test_filter_settings_agree_at_scale(engine):
     o = offs[: n + 1].cpu().numpy().astype(np.uint64)
     exp = RC.signatures(text[: int(o[-1])].cpu().numpy(), o, 128, 13, "char")
     assert (as_u32(base[:n]) == exp).all()
+
+
+@pytest.mark.parametrize("unit,width", [("word", 5), ("char", 13)])
+def test_batched_work_claims_change_nothing(engine, unit, width):
+    """300 k short documents: the work counter is claimed in batches of up to 8 items here (sig_kernel: guided
+    self-scheduling; a call on <= 16 k documents only ever takes single items).  Size-independent property: the rows
+    equal those of small calls on slices of the same corpus; both ends are checked against the oracle as well"""
+    from map_neo_amd.minhash import padded_size
+    import torch
+
+    spec = corpus.CorpusSpec(300000, 128, lang="en", dup_frac=0.1, seed=77)
+    text, offs = corpus.generate(spec, device=engine.device)
+    sig = engine.signatures(text, offs, 128, width, unit)
+    n = offs.numel() - 1
+    for lo in (0, 123457, n - 9000):
+        hi = min(n, lo + 9000)
+        b0, b1 = int(offs[lo].item()), int(offs[hi].item())
+        t = torch.zeros(padded_size(b1 - b0), dtype=torch.uint8, device=engine.device)
+        t[: b1 - b0] = text[b0:b1]
+        part = engine.signatures(t, (offs[lo : hi + 1] - b0).contiguous(), 128, width, unit)
+        assert bool((part == sig[lo:hi]).all()), (unit, lo)
+    for lo in (0, n - 300):
+        o = offs[lo : lo + 301].cpu().numpy().astype(np.uint64)
+        exp = RC.signatures(text[int(o[0]) : int(o[-1])].cpu().numpy(), o - o[0], 128, width, unit)
+        assert (as_u32(sig[lo : lo + 300]) == exp).all(), (unit, lo)
