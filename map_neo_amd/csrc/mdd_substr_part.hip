@@ -527,7 +527,9 @@ __device__ __forceinline__ void lds_sync() {
 }
 constexpr int LEAF_CH = 10;     // entries per lane and chunk: 640 = LEAF_ONE_ROUND, above nearly every leaf's size
 constexpr int LEAF_ILP = 1;     // entries a lane inserts side by side (2 measured: 29.3 vs 29.5 ms, no gain)
-constexpr int CAND_CAP = 256;   // candidate list entries (drained when a step could overflow it)
+constexpr int CAND_CAP = 128;   // candidate list entries (whole turns of 64 are drained when a step could overflow it); 256 cost
+                                // 1.25 KB more LDS per wave: 14 instead of 16 waves per CU
+constexpr unsigned LEAF_WAVES_PER_CU = 16;  // single-wave workgroups resident per CU: 16 x sizeof(LeafLds) = 148 KB of the 160 KB LDS
 struct LeafLds {
     unsigned long long tab[LEAF_SLOTS];
     unsigned long long cval[CAND_CAP];
@@ -537,6 +539,7 @@ __device__ __forceinline__ uint32_t leaf_home(unsigned long long val) {
     return ((uint32_t)(val >> POS_BITS) * 0x9E3779B1u) >> (32 - 10);
 }
 static_assert(LEAF_SLOTS == 1024, "leaf_home yields 10 bits");
+static_assert(LEAF_WAVES_PER_CU * sizeof(LeafLds) <= 160 * 1024, "the leaf kernels' workgroups must all be resident");
 
 // the full protocol for one window, from `slot` on; true = it claimed an empty slot (a new distinct content)
 __device__ __forceinline__ bool leaf_resolve(LeafLds& L, const LeafArgs& A, unsigned long long val, uint32_t slot) {
@@ -576,15 +579,26 @@ struct LeafWave {
         lds_sync();
         distinct = 0;
     }
-    __device__ __forceinline__ void drain() {
+    // all = false (the list is filling up in the middle of a leaf): only whole turns of 64 are resolved, what is left over
+    // moves to the front of the list and waits for company
+    __device__ __forceinline__ void drain(bool all) {
         lds_sync();
-        for (uint32_t base = 0; base < n_cand; base += 64) {
+        uint32_t base = 0;
+        for (; all ? base < n_cand : base + 64 <= n_cand; base += 64) {
             bool claimed = false;
             if (base + lane < n_cand) claimed = leaf_resolve(L, A, L.cval[base + lane], L.cslot[base + lane]);
             distinct += (uint32_t)__popcll(__ballot(claimed));
         }
+        const uint32_t rest = base < n_cand ? n_cand - base : 0u;  // < 64, only when !all
+        if (rest && base) {
+            unsigned long long v = 0;
+            uint16_t sl = 0;
+            if (lane < rest) v = L.cval[base + lane], sl = L.cslot[base + lane];
+            lds_sync();
+            if (lane < rest) L.cval[lane] = v, L.cslot[lane] = sl;
+        }
         lds_sync();
-        n_cand = 0;
+        n_cand = rest;
     }
     // (a rolled loop over a rotating register array: unrolled, the body -- with the candidate drain inside -- came to
     // 150 KB of code, more than the instruction cache holds)
@@ -658,7 +672,7 @@ struct LeafWave {
                 }
                 n_cand += (uint32_t)__popcll(cb);
             }
-            if (n_cand > CAND_CAP - 64 * LEAF_ILP) drain();
+            if (n_cand > CAND_CAP - 64 * LEAF_ILP) drain(false);
         }
     }
     // share r of R of the entries [lo, hi) into the (cleared) table; `first` holds the first chunk already
@@ -669,7 +683,7 @@ struct LeafWave {
             load_chunk(more, c0, hi);
             insert_chunk(more, R, r);
         }
-        drain();
+        drain(true);
         // the table is filling up: chains get long and then it is full -- refuse (mdd_substr_check)
         if (distinct > LEAF_SLOTS * 3 / 4 && lane == 0) atomicAdd(A.overflow, 1ull);
     }
@@ -910,8 +924,8 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
         }
     }
     HIP_TRY(hipMemsetAsync(big_tab, 0xFF, sizeof(uint64_t) << BIG_TAB_BITS, st));
-    hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)ctx->cus * 14), dim3(64), 0, st, L);
-    hipLaunchKernelGGL(bigleaf_kernel, dim3((unsigned)ctx->cus * 14), dim3(64), 0, st, L);  // returns at once when nothing was queued
+    hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, L);
+    hipLaunchKernelGGL(bigleaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, L);  // returns at once when nothing was queued
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

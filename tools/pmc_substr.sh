@@ -7,6 +7,8 @@ mkdir -p $OUT
 run() { name=$1; shift; timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python3 tools/substr_probe.py 1000000 sorted,sorted > $OUT/$name.log 2>&1; }
 run p1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
 run p2 TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_ANY SQ_WAVES
+run p3 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+run p4 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 python3 - <<'PY'
 import csv, glob, collections
 for f in sorted(glob.glob("gpurun_out/pmc_substr/*/*counter_collection.csv")):
