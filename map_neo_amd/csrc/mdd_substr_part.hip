@@ -61,6 +61,26 @@ __device__ __forceinline__ uint64_t wkey(const TextView& tv, uint32_t s, uint32_
     }
     return mix64(((uint64_t)h1 << 32) | h2);
 }
+// wkey for a length known at compile time (the same value as wkey(tv, s, L)): no loop control, no per-dword tests, the
+// tail mask a constant.  emit_kernel takes it for the windows of pure-ASCII segments at the default window of 50.
+template <uint32_t L>
+__device__ __forceinline__ uint64_t wkey_fixed(const TextView& tv, uint32_t s) {
+    constexpr uint32_t ND = (L + 3u) / 4u;
+    const uint32_t* src = tv.docw + (s >> 2);
+    const uint32_t sh = s & 3u;
+    uint32_t r[ND + 1];
+#pragma unroll
+    for (uint32_t j = 0; j <= ND; j++) r[j] = src[j];
+    uint32_t h1 = 0x9E3779B9u ^ L, h2 = 0x85EBCA6Bu;
+#pragma unroll
+    for (uint32_t k = 0; k < ND; k++) {
+        uint32_t w = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh);
+        if (L - 4u * k < 4u) w &= 0xFFFFFFFFu >> (8u * (4u - (L - 4u * k)));
+        h1 = __builtin_amdgcn_alignbit(h1, h1, 27) + w;
+        h2 = (__builtin_amdgcn_alignbit(h2, h2, 19) ^ w) + h1;
+    }
+    return mix64(((uint64_t)h1 << 32) | h2);
+}
 __device__ __forceinline__ uint32_t d1_of(uint64_t key) { return (uint32_t)(key >> (64 - D1_BITS)); }
 __device__ __forceinline__ uint64_t entry_of(uint64_t key, uint64_t pos) {  // [d2:11 | tag:17 | pos:36] = key bits 52..25, position
     return (((key >> (64 - D1_BITS - D2_BITS - TAG_BITS)) & ((1ULL << (D2_BITS + TAG_BITS)) - 1)) << POS_BITS) | pos;
@@ -146,7 +166,7 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                                // no gain -- a wave computes the key as long as ONE of its 64 lanes needs it)
                                // (pure-ASCII segment: every window is A.window bytes long -- a wave-uniform length lets the
                                // compiler do the loop control and the tail mask of the key on the scalar unit)
-                               key = ascii ? wkey(tv, s, A.window) : wkey(tv, s, L);
+                               key = ascii ? (A.window == 50u ? wkey_fixed<50>(tv, s) : wkey(tv, s, A.window)) : wkey(tv, s, L);
                                if (A.n_parts > 1 && (uint32_t)((key & 0x3FFFu) % A.n_parts) != A.part) on = false;
                            }
                            const uint64_t bal = __ballot(on);
