@@ -36,6 +36,9 @@ constexpr int LEAF_SLOTS = 1024;  // LDS table entries per leaf (one wave per le
 // issues at a quarter of the rate, so the multiplies (mix64) come once per window, not once per dword as in win_kernel's
 // window_key -- and the dwords are loaded eight at a time (a loop of single dependent loads left the kernel waiting on
 // the L1 round trip thirteen times per window).
+// (A one-multiply step, h' = (lo32(h) ^ w) * C + h as a single v_mad_u64_u32, is two instructions instead of five, but it is
+// not a bijection of the state: on repetitive text distinct windows pile into single leaves -- test_substr_sorted_method_big_leaves
+// then reports windows without room -- so the step stays add / rotate / xor.)
 __device__ __forceinline__ uint64_t wkey(const TextView& tv, uint32_t s, uint32_t L) {
     const uint32_t* src = tv.docw + (s >> 2);
     const uint32_t sh = s & 3u;
