@@ -70,3 +70,13 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), encoding="utf8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "ref_py" not in txt and "libmdd_ref" not in txt, f
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's appendix maps every exported entry point to what it replaces in the reference"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in _header_symbols() if s not in doc]
+    assert not missing, missing
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdd_io.h")).read(), flags=re.S)
+    for s in sorted(set(re.findall(r"\b(mdd_io_[a-z0-9_]+)\s*\(", src))):
+        assert s in doc or ("`" + s[len("mdd_io"):] + "`") in doc, s
