@@ -73,13 +73,24 @@ def shingles_char(text: str, width: int = WIDTH) -> List[bytes]:
 
 def shingles_word(text: str, n: int) -> List[bytes]:
     """Parameter extension (BASELINE.json config 1, 'n-gram words'; not in the reference):
-    nltk.ngrams(text.split(' '), n) over space-separated tokens of the already-normalised
-    text, joined with one space, utf-8 encoded.  Tokens are maximal runs of non-space
-    bytes (0x20 is the only separator), so the shingle equals the text substring from the
-    first token's start to the last token's end."""
-    toks = [t for t in text.split(' ') if t != '']
-    m = len(toks) - n + 1
-    return [' '.join(toks[i:i + n]).encode('utf8') for i in range(max(0, m))]
+    nltk.ngrams(tokens, n) over the space-separated tokens of the already-normalised text,
+    joined with one space, utf-8 encoded.  Tokens are maximal runs of non-space characters
+    (0x20 is the only separator) and the shingle is the text from the first token's start to
+    the last token's end -- on normalised text (single spaces, EN:31-40) exactly
+    ' '.join(tokens[i:i+n]); on text with runs of spaces the run stays inside the shingle
+    (what the C restatement and the device kernel hash: no copy of the tokens is made)."""
+    spans, i, L = [], 0, len(text)
+    while i < L:
+        if text[i] == ' ':
+            i += 1
+            continue
+        j = i
+        while j < L and text[j] != ' ':
+            j += 1
+        spans.append((i, j))
+        i = j
+    m = len(spans) - n + 1
+    return [text[spans[k][0]:spans[k + n - 1][1]].encode('utf8') for k in range(max(0, m))]
 
 
 def shingles(text: str, unit: str = 'char', width: int = WIDTH) -> List[bytes]:

@@ -571,3 +571,30 @@ def test_signature_matches_and_min_jaccard_vs_oracle(engine):
     assert 0 < len(kept) < len(eu)
     assert np.array_equal(as_u32(res["labels"]), R.components_min_label(spec.n_docs, kept))
     assert int(res["n_removed"].item()) < int(plain["n_removed"].item())
+
+
+@pytest.mark.parametrize("seg", [0, 256])
+def test_word_scan_window_and_segment_boundaries(engine, seg):
+    """The word-unit boundary scan works on 256-byte windows, one dword per lane, and carries three facts from window to
+    window (the previous byte was a space, a token spans the window's first byte, a segment began inside a token):
+    documents whose lengths sit around multiples of 256, with spaces sparse, dense and in runs, leading / trailing
+    spaces, tokens longer than a window and 3-byte code points -- against the oracle, whole and cut into 256-byte segments"""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    docs = []
+    for ln in (0, 1, 3, 4, 5, 252, 255, 256, 257, 260, 508, 511, 512, 513, 516, 767, 768, 769, 1023, 1024, 1025, 2049):
+        for p_space in (0.0, 0.02, 0.3, 0.7, 0.97):
+            ch = np.where(rng.random(ln) < p_space, " ", np.where(rng.random(ln) < 0.1, "中", "a"))
+            s = "".join(ch.tolist())
+            docs.append(s)
+            docs.append(" " + s + "  ")
+    docs.append("a" * 700 + " b c d e f " + "g" * 300)
+    text, offs_d, buf, offs = _dev(engine, docs)
+    engine.set_segment_bytes(seg)
+    try:
+        for width in (1, 2, 5):
+            got = as_u32(engine.signatures(text, offs_d, 64, width, "word"))
+            exp = RC.signatures(buf, offs, 64, width, "word")
+            bad = np.nonzero((got != exp).any(axis=1))[0]
+            assert bad.size == 0, (seg, width, bad[:5], [len(docs[i]) for i in bad[:5]])
+    finally:
+        engine.set_segment_bytes(0)

@@ -180,3 +180,25 @@ def test_exact_stage_oracle_matches_golden():
     assert [list(x) for x in RX.paragraph_dedup(list(zip(ids, docs)), 0)] == g["paragraph_min_len_0"]
     assert [list(x) for x in RX.exact_substr_dedup(list(zip(docs, ids)), 50, 20)] == g["substr_50_20"]
     assert [list(x) for x in RX.exact_substr_dedup(list(zip(docs, ids)), 13, 0)] == g["substr_13_0"]
+
+
+def test_word_unit_on_runs_of_spaces_both_oracles():
+    """The word unit (an extension, BASELINE.json config 1) is defined on normalised text; on runs of spaces, leading and
+    trailing spaces both restatements hash the text from the first token's start to the last token's end"""
+    from map_neo_amd.minhash import pack_texts
+
+    assert R.shingles_word("a b  c", 2) == [b"a b", b"b  c"]
+    assert R.shingles_word("  a   ", 1) == [b"a"] and R.shingles_word("   ", 1) == []
+    assert R.shingles_word("x y z", 2) == [b"x y", b"y z"]  # normalised text: ' '.join of the tokens
+    rng = np.random.Generator(np.random.PCG64(1))
+    docs = []
+    for ln in (0, 1, 5, 255, 256, 257, 513):
+        for p in (0.0, 0.3, 0.97):
+            ch = np.where(rng.random(ln) < p, " ", np.where(rng.random(ln) < 0.1, "中", "a"))
+            s = "".join(ch.tolist())
+            docs += [s, " " + s + "  "]
+    buf, offs = pack_texts(docs)
+    for w in (1, 2, 5):
+        a = RC.signatures(buf, offs, 64, w, "word")
+        b = np.stack([R.signature(d, 64, w, "word") for d in docs])
+        assert (a == b).all(), w
