@@ -598,3 +598,25 @@ def test_word_scan_window_and_segment_boundaries(engine, seg):
             assert bad.size == 0, (seg, width, bad[:5], [len(docs[i]) for i in bad[:5]])
     finally:
         engine.set_segment_bytes(0)
+
+
+@pytest.mark.parametrize("seg", [0, 256])
+def test_char_scan_window_and_segment_boundaries(engine, seg):
+    """The code-point scan of non-ASCII documents (SWAR start flags, ranks from three count planes): 1-, 2-, 3- and 4-byte
+    code points in every mix, document lengths around multiples of the 256-byte window, whole and in 256-byte segments"""
+    rng = np.random.Generator(np.random.PCG64(777))
+    alphabet = np.array(["a", "é", "中", "😀"])
+    docs = []
+    for n_cp in (1, 12, 13, 14, 63, 64, 65, 85, 86, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 1025):
+        for probs in ((0.97, 0.01, 0.01, 0.01), (0.25, 0.25, 0.25, 0.25), (0.0, 0.0, 1.0, 0.0), (0.0, 0.0, 0.02, 0.98), (0.5, 0.0, 0.5, 0.0)):
+            docs.append("".join(rng.choice(alphabet, n_cp, p=probs).tolist()))
+    text, offs_d, buf, offs = _dev(engine, docs)
+    engine.set_segment_bytes(seg)
+    try:
+        for width in (1, 13, 40):
+            got = as_u32(engine.signatures(text, offs_d, 64, width, "char"))
+            exp = RC.signatures(buf, offs, 64, width, "char")
+            bad = np.nonzero((got != exp).any(axis=1))[0]
+            assert bad.size == 0, (seg, width, bad[:5], [len(docs[i]) for i in bad[:5]])
+    finally:
+        engine.set_segment_bytes(0)
