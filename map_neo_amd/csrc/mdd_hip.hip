@@ -1166,6 +1166,9 @@ int mdd_make_perms(uint32_t seed, int K, uint64_t* a_host, uint64_t* b_host) {
 // Shared body of mdd_signatures / mdd_signatures_noalloc.  `items` (item_cap entries) is the segment queue,
 // cnt[0] the queued-segment count, cnt[1] the work counter.  grow: a queue too small for text_bytes / seg_bytes
 // segments is handled by longer segments (mdd_signatures); otherwise the call is rejected (noalloc variant).
+#ifndef MDD_MAX_BATCH  // most work items one claim takes (signatures_impl)
+#define MDD_MAX_BATCH 8
+#endif
 static int signatures_impl(const char* fn, mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
                            uint64_t n_docs, int unit, int width, int K, const uint64_t* a, const uint64_t* b, uint32_t* sig_out,
                            uint64_t* items, uint64_t* cnt, uint64_t item_cap, bool grow, const StreamIn* in = nullptr) {
@@ -1230,7 +1233,7 @@ static int signatures_impl(const char* fn, mdd_ctx* ctx, const uint8_t* text, ui
     {
         const uint64_t avg = text_bytes / n_docs + 1, rate = unit == MDD_UNIT_CHAR ? 4096 : 8192;
         const uint64_t mb = (rate + avg - 1) / avg;
-        A.max_batch = (uint32_t)(mb < 1 ? 1 : (mb > 8 ? 8 : mb));
+        A.max_batch = (uint32_t)(mb < 1 ? 1 : (mb > MDD_MAX_BATCH ? MDD_MAX_BATCH : mb));
     }
     return launch_sig<false>(ctx, A, grid_for(waves, WAVES));
 }

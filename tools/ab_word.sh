@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of sig_bench builds (build/sig_bench_head = the previous commit's kernel; _bN = -DMDD_MAX_BATCH=N) on the C2 corpus
+# A/B of sig_bench builds on the C2 corpus.  build/sig_bench_head = tools/sig_bench.hip of the commit to compare with, built in a
+# scratch worktree (git worktree add /tmp/w <commit>; hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -o build/sig_bench_head tools/sig_bench.hip)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/ab; mkdir -p $OUT
