@@ -44,6 +44,7 @@ struct WinArgs {
     uint8_t* dup;
     unsigned long long* overflow;  // windows that found neither their content nor a free slot (table too small)
     uint32_t part, n_parts;  // this launch handles the windows whose key falls into partition `part` of `n_parts`
+    uint32_t batch_shift;    // a claim on the work counter takes (items left) >> batch_shift items, clamped to [1, 8]
 };
 
 // 4 bytes at byte address p of the text (any alignment); reads at most 7 bytes past p
@@ -90,17 +91,24 @@ __global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
     const uint32_t* tw = reinterpret_cast<const uint32_t*>(A.text);
     const uint64_t extra = *A.n_items;  // final: seg_plan_kernel ran before this kernel on the stream
     const uint64_t total = A.n_docs + (extra < A.max_items ? extra : A.max_items);
-    // persistent waves pulling documents (then queued segments of long documents) from one counter;
+    // persistent waves claiming documents (then queued segments of long documents) from one counter, in batches (guided
+    // self-scheduling as in sig_kernel, mdd_hip.hip: a same-address atomic costs ~11 ns and the wave waits for it);
     // every wave leaves once the counter passes `total`
-    auto fetch = [&]() -> uint64_t {
+    auto fetch = [&](uint32_t n) -> uint64_t {
         unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(A.work_counter, 1ull);
+        if (lane == 0) v = atomicAdd(A.work_counter, (unsigned long long)n);
         uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
         return ((uint64_t)hi << 32) | lo;
     };
-    uint64_t item = fetch();
-    while (item < total) {
-        uint64_t next_item = fetch();
+    uint64_t item = 0, batch_end = 0;
+    for (;; item++) {
+        if (item >= batch_end) {  // `item` = end of this wave's previous batch: a lower bound of the counter
+            const uint64_t want = (total > item ? total - item : 0) >> A.batch_shift;
+            const uint32_t n = want < 1u ? 1u : (want > 8u ? 8u : (uint32_t)want);
+            item = fetch(n);
+            if (item >= total) break;
+            batch_end = item + n < total ? item + n : total;
+        }
         uint64_t d = item;
         uint32_t seg = 0;
         if (d >= A.n_docs) {
@@ -148,7 +156,6 @@ __global__ void __launch_bounds__(64) win_kernel(WinArgs A) {
                            }
                            atomicAdd(A.overflow, 1ull);
                        });
-        item = next_item;
     }
 }
 
@@ -404,6 +411,7 @@ extern "C" int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_
                        A.seg_bytes, ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items,
                        (uint32_t*)nullptr, 0);
     HIP_TRY(hipGetLastError());
+    while ((1ull << A.batch_shift) < waves * 4) A.batch_shift++;
     hipLaunchKernelGGL(win_kernel, dim3((unsigned)waves), dim3(64), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
