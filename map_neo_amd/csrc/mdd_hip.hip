@@ -317,6 +317,9 @@ __device__ __forceinline__ bool wait_ready(const StreamIn& S, uint64_t need) {
 #ifndef MDD_WPE  // waves per SIMD the register budget is set for.  The filtered permute phase is a chain of
 #define MDD_WPE 4  // dependent mad -> min -> cmp -> branch, so a 4th wave pays (+5 % ASCII, +9 % word 5-grams)
 #endif             // although 4-12 VGPRs of the non-ASCII boundary scan then live in scratch; 5 and 6 are slower
+#ifndef MDD_FILTER_G_WIDE  // hashes per filter group at K > 128 (3 or 4 permutations per lane); 8 re-measured at K = 256: 77.2 -> 80.3 ms
+#define MDD_FILTER_G_WIDE 4
+#endif
 #ifndef MDD_FILTER_FROM  // shingles of a work item hashed in full, per 64 permutations of K, before the
 #define MDD_FILTER_FROM 256  // permute phase starts filtering (measured: 512 at K = 128, 1024 at K = 256)
 #endif
@@ -493,7 +496,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                             uint32_t g[KPL];
 #pragma unroll
                             for (int q = 0; q < KPL; q++) g[q] = (m[q] < 0xFFFFFFF9u ? m[q] : 0xFFFFFFF9u) + 6u;
-                            constexpr int G = KPL <= 2 ? 8 : 4;      // hashes per filter group (measured best)
+                            constexpr int G = KPL <= 2 ? 8 : MDD_FILTER_G_WIDE;  // hashes per filter group (measured best)
                             const uint32_t ng = (n4 * 4u + G - 1) / G;  // all 64 words of hbuf are written: an over-read stays in range
                             for (uint32_t i = 0; i < ng; i++) {
                                 MDD_REGION("fgroup", PR_FGROUP);
