@@ -136,10 +136,15 @@ __device__ __forceinline__ void sha1_compress(uint32_t (&st)[5], uint32_t (&w)[1
 
 // Big-endian message word covering message bytes [pos, pos+4) of a message of L bytes,
 // rem = L - pos: data bytes, then the 0x80 pad, then zeros.  (lo,hi) are the two aligned
-// little-endian dwords that contain the 4 bytes at byte shift sh.
-__device__ __forceinline__ uint32_t msg_word(uint32_t lo, uint32_t hi, uint32_t sh, int rem) {
-    uint32_t le = __builtin_amdgcn_alignbyte(hi, lo, sh);
-    uint32_t be = __builtin_bswap32(le);
+// little-endian dwords that contain the 4 bytes at byte shift sh; sel = msg_sel(sh).
+// ONE v_perm_b32 both aligns and byte-swaps: result byte 3 (the word's first message byte) = byte sh of {hi:lo},
+// byte 2 = byte sh+1, ... (v_alignbyte + the v_perm of a bswap32 were two half-rate instructions per word).
+__device__ __forceinline__ uint32_t msg_sel(uint32_t sh) { return 0x00010203u + sh * 0x01010101u; }
+// FUSED = false: sel is the byte shift itself, v_alignbyte + bswap32 -- kept for the ASCII width-13 tier, whose four words
+// gain one instruction from the fused form and whose schedule came out 2 % slower with it (54.4 -> 55.5 ms at C2).
+template <bool FUSED = true>
+__device__ __forceinline__ uint32_t msg_word(uint32_t lo, uint32_t hi, uint32_t sel, int rem) {
+    uint32_t be = FUSED ? __builtin_amdgcn_perm(hi, lo, sel) : __builtin_bswap32(__builtin_amdgcn_alignbyte(hi, lo, sel));
     if (rem >= 4) return be;
     if (rem < 0) return 0u;
     uint32_t keep = ~(0xFFFFFFFFu >> (8 * rem));
@@ -155,13 +160,14 @@ template <int NW, int FIXEDL>
 __device__ __forceinline__ uint32_t hash_single(const TextView& tv, uint32_t p, uint32_t L) {
     if (FIXEDL > 0) L = FIXEDL;
     uint32_t base = p >> 2;
-    uint32_t sh = p & 3u;
+    constexpr bool FUSED = !(NW == 4 && FIXEDL == 13);
+    const uint32_t sel = FUSED ? msg_sel(p & 3u) : (p & 3u);
     uint32_t dw[NW + 1];
 #pragma unroll
     for (int k = 0; k <= NW; k++) dw[k] = ld_dword(tv, base + k);
     uint32_t w[16];
 #pragma unroll
-    for (int k = 0; k < NW; k++) w[k] = msg_word(dw[k], dw[k + 1], sh, (int)L - 4 * k);
+    for (int k = 0; k < NW; k++) w[k] = msg_word<FUSED>(dw[k], dw[k + 1], sel, (int)L - 4 * k);
 #pragma unroll
     for (int k = NW; k < 15; k++) w[k] = 0u;
     w[15] = L * 8u;
@@ -173,7 +179,7 @@ __device__ __forceinline__ uint32_t hash_single(const TextView& tv, uint32_t p, 
 // any length (multi-block); lanes may run different block counts
 __device__ __noinline__ uint32_t hash_multi(const uint32_t* docw, uint32_t p, uint32_t L) {
     uint32_t base = p >> 2;
-    uint32_t sh = p & 3u;
+    const uint32_t sel = msg_sel(p & 3u);
     uint32_t nblk = (L + 8u) / 64u + 1u;
     uint32_t st[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
     for (uint32_t bi = 0; bi < nblk; bi++) {
@@ -185,7 +191,7 @@ __device__ __noinline__ uint32_t hash_multi(const uint32_t* docw, uint32_t p, ui
             // load far past the shingle (keeps every access within MDD_TEXT_PAD of the text)
             int rem = (int)L - (int)(64u * bi) - 4 * k;
             uint32_t hi = rem > -4 ? docw[base + 16u * bi + k + 1] : 0u;
-            w[k] = msg_word(lo, hi, sh, rem);
+            w[k] = msg_word(lo, hi, sel, rem);
             lo = hi;
         }
         if (bi == nblk - 1) w[15] = L * 8u;  // L < 2^29 is enforced on the host
