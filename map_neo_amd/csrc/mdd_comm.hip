@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -34,14 +35,31 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
 
+// No single message exceeds this many bytes: RCCL on this stack was seen to drop the tail of an exchange beyond 1 GiB
+// (tools/diag_a2a.py); larger transfers go in rounds.  Both ends of a pair know the pair's size, so they cut it alike.
+// TEST HOOK: MDD_COMM_MSG_BYTES (>= 64) lowers the limit so that small exchanges run in several rounds.
+uint64_t g_msg_bytes = 512ull << 20;
+
 int load_rccl() {
     if (g_rccl.handle) return MDD_OK;
     void* h = nullptr;
-    // an already loaded RCCL first (torch's), then the usual names
-    for (const char* name : {"librccl.so", "librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        if (h) break;
+    if (const char* e = getenv("MDD_COMM_MSG_BYTES")) {
+        unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 64 && v <= (512ull << 20)) g_msg_bytes = v;
     }
+    // TEST HOOK: MDD_RCCL_LIB names the library to bind instead of RCCL (tests/native/fake_rccl.cpp: a loop-back
+    // transport that lets W > 1 ranks run as threads on one GPU).  Not for production use.
+    const char* forced = getenv("MDD_RCCL_LIB");
+    if (forced && forced[0]) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(MDD_ERR_UNSUPPORTED, "mdd_comm: cannot load MDD_RCCL_LIB=%s (%s)", forced, dlerror());
+    }
+    // an already loaded RCCL first (torch's), then the usual names
+    if (!h)
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (h) break;
+        }
     if (!h)
         for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -75,9 +93,17 @@ int load_rccl() {
             return mddi::fail(MDD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
-// No single message exceeds this many bytes: RCCL on this stack was seen to drop the tail of an exchange beyond 1 GiB
-// (tools/diag_a2a.py); larger transfers go in rounds.  Both ends of a pair know the pair's size, so they cut it alike.
-constexpr uint64_t MSG_BYTES = 512ull << 20;
+// Inside an open ncclGroupStart: a failing call must not leave the communicator in group mode (later collectives of
+// this process -- torch's included, it is the same RCCL -- would queue behind a group that never ends).  ncclGroupEnd
+// after a failed call drops the group and reports the error again; its result is ignored here.
+#define NCCL_GROUP_TRY(expr)                                                                                         \
+    do {                                                                                                             \
+        ncclResult_t r_ = (expr);                                                                                    \
+        if (r_ != ncclSuccess) {                                                                                     \
+            (void)g_rccl.GroupEnd();                                                                                 \
+            return mddi::fail(MDD_ERR_HIP, "%s failed inside a group: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+        }                                                                                                            \
+    } while (0)
 
 int need_comm(const char* fn, mdd_ctx* ctx) {
     REQUIRE(ctx != nullptr, "%s: ctx is NULL", fn);
@@ -99,7 +125,7 @@ int alltoallv(mdd_ctx* ctx, int narr, const void* const* send, void* const* recv
     REQUIRE(send_counts[me] == recv_counts[me], "mdd_comm: a rank's count of records for itself differs between send and recv");
     uint32_t rec_bytes = 0;
     for (int a = 0; a < narr; a++) rec_bytes = rec_bytes > width[a] * elem[a] ? rec_bytes : width[a] * elem[a];
-    const uint64_t per_round = MSG_BYTES / rec_bytes;  // records of one pair per round
+    const uint64_t per_round = g_msg_bytes / rec_bytes ? g_msg_bytes / rec_bytes : 1;  // records of one pair per round
     uint64_t most = 0;
     for (int p = 0; p < W; p++) {
         if (p == me) continue;
@@ -122,8 +148,8 @@ int alltoallv(mdd_ctx* ctx, int narr, const void* const* send, void* const* recv
             uint64_t nr = recv_counts[p] > done ? (recv_counts[p] - done < per_round ? recv_counts[p] - done : per_round) : 0;
             for (int a = 0; a < narr; a++) {
                 const uint64_t eb = (uint64_t)width[a] * elem[a];
-                if (ns) NCCL_TRY(g_rccl.Send(static_cast<const char*>(send[a]) + (soff[p] + done) * eb, ns * eb, ncclUint8, p, comm, ctx->stream));
-                if (nr) NCCL_TRY(g_rccl.Recv(static_cast<char*>(recv[a]) + (roff[p] + done) * eb, nr * eb, ncclUint8, p, comm, ctx->stream));
+                if (ns) NCCL_GROUP_TRY(g_rccl.Send(static_cast<const char*>(send[a]) + (soff[p] + done) * eb, ns * eb, ncclUint8, p, comm, ctx->stream));
+                if (nr) NCCL_GROUP_TRY(g_rccl.Recv(static_cast<char*>(recv[a]) + (roff[p] + done) * eb, nr * eb, ncclUint8, p, comm, ctx->stream));
             }
         }
         NCCL_TRY(g_rccl.GroupEnd());
@@ -197,8 +223,8 @@ int mdd_exchange_counts(mdd_ctx* ctx, const uint64_t* send_counts, uint64_t* sen
         NCCL_TRY(g_rccl.GroupStart());
         for (int p = 0; p < W; p++) {
             if (p == me) continue;
-            NCCL_TRY(g_rccl.Send(send_counts + p, 1, ncclUint64, p, comm, ctx->stream));
-            NCCL_TRY(g_rccl.Recv(rdev + p, 1, ncclUint64, p, comm, ctx->stream));
+            NCCL_GROUP_TRY(g_rccl.Send(send_counts + p, 1, ncclUint64, p, comm, ctx->stream));
+            NCCL_GROUP_TRY(g_rccl.Recv(rdev + p, 1, ncclUint64, p, comm, ctx->stream));
         }
         NCCL_TRY(g_rccl.GroupEnd());
     }
@@ -266,7 +292,7 @@ int mdd_allgather_edges(mdd_ctx* ctx, const uint32_t* edge_u, const uint32_t* ed
         HIP_TRY(hipMemcpyAsync(all_u + off[me], edge_u, mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(all_v + off[me], edge_v, mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    const uint64_t per_round = MSG_BYTES / 4;
+    const uint64_t per_round = g_msg_bytes / 4;
     uint64_t most = 0;
     for (int p = 0; p < W; p++) most = most > counts_host[p] ? most : counts_host[p];
     for (uint64_t done = 0; W > 1 && done < most; done += per_round) {
@@ -276,12 +302,12 @@ int mdd_allgather_edges(mdd_ctx* ctx, const uint32_t* edge_u, const uint32_t* ed
             if (p == me) continue;
             uint64_t nr = counts_host[p] > done ? (counts_host[p] - done < per_round ? counts_host[p] - done : per_round) : 0;
             if (ns) {
-                NCCL_TRY(g_rccl.Send(edge_u + done, ns, ncclUint32, p, comm, ctx->stream));
-                NCCL_TRY(g_rccl.Send(edge_v + done, ns, ncclUint32, p, comm, ctx->stream));
+                NCCL_GROUP_TRY(g_rccl.Send(edge_u + done, ns, ncclUint32, p, comm, ctx->stream));
+                NCCL_GROUP_TRY(g_rccl.Send(edge_v + done, ns, ncclUint32, p, comm, ctx->stream));
             }
             if (nr) {
-                NCCL_TRY(g_rccl.Recv(all_u + off[p] + done, nr, ncclUint32, p, comm, ctx->stream));
-                NCCL_TRY(g_rccl.Recv(all_v + off[p] + done, nr, ncclUint32, p, comm, ctx->stream));
+                NCCL_GROUP_TRY(g_rccl.Recv(all_u + off[p] + done, nr, ncclUint32, p, comm, ctx->stream));
+                NCCL_GROUP_TRY(g_rccl.Recv(all_v + off[p] + done, nr, ncclUint32, p, comm, ctx->stream));
             }
         }
         NCCL_TRY(g_rccl.GroupEnd());

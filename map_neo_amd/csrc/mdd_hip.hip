@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 
 #include "mdd_common.h"
@@ -238,7 +239,8 @@ __device__ __forceinline__ uint32_t hash_any(const TextView& tv, uint32_t p, uin
 // ------------------------------------------------------------------------------------------
 struct StreamIn {
     const uint64_t* host_flag;  // pinned host word (device-visible address) the copy stream's host functions advance
-    uint64_t* words;            // device: [0] = highest flag value any wave has read, [1] = status, [2] = poller lock
+    uint64_t* words;            // device: [0] = highest flag value any wave has read, [1] = status of this launch, [2] = poller lock,
+                                // [3] = wait ticks, [4] = sticky status (a launch since the last mdd_ctx_sync gave up)
     uint64_t base;              // flag value at which this call's text has 0 bytes (the flag only ever grows)
 };
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
@@ -313,7 +315,10 @@ __device__ __forceinline__ bool wait_ready(const StreamIn& S, uint64_t need) {
         uint64_t now = uni64(wall_clock64());
         if (spin == 0) t0 = now;
         else if (now - t0 > STREAM_TIMEOUT_TICKS) {
-            if (lane_id() == 0) atomicOr(reinterpret_cast<unsigned long long*>(S.words + 1), 1ull);
+            if (lane_id() == 0) {
+                atomicOr(reinterpret_cast<unsigned long long*>(S.words + 1), 1ull);  // this launch: every wave leaves
+                atomicOr(reinterpret_cast<unsigned long long*>(S.words + 4), 1ull);  // sticky: only mdd_ctx_sync clears it
+            }
             return false;
         }
         __builtin_amdgcn_s_sleep(64);
@@ -1083,14 +1088,14 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     c->seg_bytes = SEG_BYTES_DEFAULT;
     c->filter_from = 0;
     c->seg_items = nullptr;
-    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 8) * sizeof(uint64_t));
-    if (me == hipSuccess) me = hipMemset(c->seg_items + SEG_ITEM_CAP, 0, 8 * sizeof(uint64_t));
+    hipError_t me = hipMalloc(&c->seg_items, (SEG_ITEM_CAP + 16) * sizeof(uint64_t));
+    if (me == hipSuccess) me = hipMemset(c->seg_items + SEG_ITEM_CAP, 0, 16 * sizeof(uint64_t));
     if (me != hipSuccess) {
         delete c;
         return fail(MDD_ERR_HIP, "mdd_ctx_create: hipMalloc of the segment plan failed: %s", hipGetErrorString(me));
     }
     c->seg_n_items = c->seg_items + SEG_ITEM_CAP;  // [0] = queued segments, [1] = work counter, [2] = win_kernel probe overflows
-    c->stream_words = c->seg_items + SEG_ITEM_CAP + 4;  // 3 more words of the same allocation (zeroed above)
+    c->stream_words = c->seg_items + SEG_ITEM_CAP + 4;  // 5 more words of the same allocation (zeroed above)
     c->stream_base = 0;
     c->comm = nullptr;
     c->comm_rank = 0;
@@ -1136,13 +1141,18 @@ int mdd_ctx_destroy(mdd_ctx* ctx) {
 int mdd_ctx_sync(mdd_ctx* ctx) {
     REQUIRE(ctx != nullptr, "mdd_ctx_sync: ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->stream_pending) {  // did a wave of a streamed launch give up waiting for its input?
+    if (ctx->stream_pending) {  // did a wave of ANY streamed launch since the last sync give up waiting for its input?
         ctx->stream_pending = false;
+        // the per-launch status word is cleared by every call (a later launch must not leave at once), so the verdict is
+        // kept in a sticky word that only this function clears: a time-out of call N is still reported after call N+1
         uint64_t st = 0;
-        HIP_TRY(hipMemcpy(&st, ctx->stream_words + 1, sizeof st, hipMemcpyDeviceToHost));
-        if (st)
-            return fail(MDD_ERR_HIP, "mdd_signatures_from_host: the kernel waited more than 4 s for text that never arrived "
-                                     "(copy stream stalled or failed); the signatures are incomplete");
+        HIP_TRY(hipMemcpy(&st, ctx->stream_words + 4, sizeof st, hipMemcpyDeviceToHost));
+        if (st) {
+            HIP_TRY(hipMemset(ctx->stream_words + 4, 0, sizeof st));
+            return fail(MDD_ERR_HIP, "mdd_signatures_from_host: a kernel waited more than 4 s for text that never arrived "
+                                     "(copy stream stalled or failed); the signatures of the streamed calls since the last "
+                                     "mdd_ctx_sync are incomplete");
+        }
     }
     return MDD_OK;
 }
@@ -1287,15 +1297,36 @@ int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* tex
     REQUIRE(n_docs <= 0x7FF00000ull * WAVES && n_docs < (1ull << 40), "mdd_signatures_from_host: n_docs too large for one launch");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t cs = (hipStream_t)copy_stream;
+    if (ctx->stream == nullptr) {
+        // the legacy default stream synchronises implicitly with every BLOCKING stream: the copies would wait for the
+        // polling kernel and the kernel for the copies, and every call would end in the 4 s time-out
+        unsigned int flags = 0;
+        HIP_TRY(hipStreamGetFlags(cs, &flags));
+        REQUIRE((flags & hipStreamNonBlocking) != 0,
+                "mdd_signatures_from_host: with a context on the default (NULL) stream, copy_stream must be created with hipStreamNonBlocking");
+    }
     if (!ctx->ready_host) {  // first streamed call on this context: set-up (never on a later call)
+        // all or nothing: ctx->ready_host is assigned last, so a failure half-way leaves the context as it was
         void* hp = nullptr;
-        HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocDefault));
+        uint64_t* flag_dev = nullptr;
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        hipError_t se = hipHostMalloc(&hp, 64, hipHostMallocDefault);
+        if (se == hipSuccess) se = hipHostGetDevicePointer(reinterpret_cast<void**>(&flag_dev), hp, 0);
+        for (int i = 0; i < 3 && se == hipSuccess; i++) se = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        ReadyNote* notes = se == hipSuccess ? new (std::nothrow) ReadyNote[2 * READY_SLOTS] : nullptr;
+        if (se != hipSuccess || !notes) {
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+            if (hp) (void)hipHostFree(hp);
+            return fail(MDD_ERR_HIP, "mdd_signatures_from_host: set-up failed: %s", se != hipSuccess ? hipGetErrorString(se) : "out of host memory");
+        }
+        *static_cast<volatile uint64_t*>(hp) = 0;
+        ctx->ready_flag_dev = flag_dev;
+        ctx->notes = notes;
+        ctx->stream_ev[0] = ev[0];
+        ctx->stream_ev[1] = ev[1];
+        ctx->order_ev = ev[2];
         ctx->ready_host = static_cast<volatile uint64_t*>(hp);
-        *ctx->ready_host = 0;
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->ready_flag_dev), hp, 0));
-        ctx->notes = new ReadyNote[2 * READY_SLOTS];
-        for (hipEvent_t* e : {&ctx->stream_ev[0], &ctx->stream_ev[1], &ctx->order_ev})
-            HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     const uint32_t half = ctx->stream_calls & 1u;
     if (ctx->stream_calls >= 2) HIP_TRY(hipEventSynchronize(ctx->stream_ev[half]));  // the host functions that read this half have run

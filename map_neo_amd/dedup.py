@@ -196,6 +196,10 @@ class TorchComm:
         return _all_gather_v(eu, self.group), _all_gather_v(ev, self.group)
 
 
+class CommInitError(RuntimeError):
+    """mdd_comm_init did not succeed on every rank"""
+
+
 class NativeComm:
     """The exchanges issued by libmdd_hip.so itself (include/mdd.h: mdd_comm_init, mdd_exchange_counts / _bands,
     mdd_allgather_counts / _edges) against RCCL, on the engine's stream; torch only owns the buffers.  The
@@ -211,7 +215,32 @@ class NativeComm:
         box = [engine.comm_unique_id() if self.rank == 0 else None]
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        engine.comm_init(box[0], self.rank, self.world)
+        # mdd_comm_init is collective, but a rank can still fail on its own after ncclCommInitRank (staging allocation):
+        # agree on the outcome, so that either every rank uses the native transport or none does
+        ok, why = 1, ""
+        try:
+            engine.comm_init(box[0], self.rank, self.world)
+        except Exception as e:      # noqa: BLE001 -- the other ranks must hear of it whatever it was
+            ok, why = 0, repr(e)
+        if self.world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=engine.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            all_ok = int(flag.item()) == 1
+        else:
+            all_ok = ok == 1
+        if not all_ok:
+            if ok:
+                engine.comm_destroy()
+            raise CommInitError(why or "mdd_comm_init failed on another rank")
+
+    @classmethod
+    def from_unique_id(cls, engine, unique_id: bytes, rank: int, world: int):
+        """For launchers without torch.distributed (one thread or process per GPU that hands rank 0's
+        Engine.comm_unique_id() to the others by its own means): collective, every rank calls it."""
+        self = cls.__new__(cls)
+        self.eng, self.rank, self.world = engine, int(rank), int(world)
+        engine.comm_init(unique_id, self.rank, self.world)
+        return self
 
     def exchange(self, tuples_s, meta_s, send_counts, rows):
         return self.eng.exchange_bands(tuples_s, meta_s, send_counts, rows)
@@ -247,7 +276,13 @@ def default_comm(be, group=None):
                   "torch.distributed on this run" % (why or "another rank failed"), file=sys.stderr, flush=True)
             comm = TorchComm(group)
         else:
-            comm = NativeComm(be, group)
+            try:
+                comm = NativeComm(be, group)
+            except CommInitError as e:
+                import sys
+                print("map_neo_amd: mdd_comm_init did not succeed on every rank (%s): the exchanges go through "
+                      "torch.distributed on this run" % e, file=sys.stderr, flush=True)
+                comm = TorchComm(group)
         be._native_comm = comm
     return comm
 
@@ -274,11 +309,14 @@ def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, ban
     band records -> all-to-all by bucket owner -> local buckets -> spanning forest -> all-gather ->
     replicated union-find.  Same return value as dedup_distributed.  `comm` carries the two exchanges
     (default_comm: libmdd_hip + RCCL for the HIP engine, torch.distributed for tests)."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    n_local = sig.shape[0]
     if comm is None:
         comm = default_comm(be, group)
+    if getattr(comm, "world", None) is not None:      # NativeComm knows its communicator (and may run without torch.distributed)
+        world, rank = comm.world, comm.rank
+    else:
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_local = sig.shape[0]
     mark = timer.mark if timer is not None else (lambda name: None)
     key, meta = be.band_keys(sig, bands, rows, doc_base, key_bits)
     mark("band_keys")
@@ -314,7 +352,7 @@ def cluster_distributed(be, sig: torch.Tensor, doc_base: int, n_global: int, ban
         timings["transport"] = comm.name
         timings["records_sent"] = int(sum(send_list))
         timings["records_received"] = int(sum(recv_list))
-        timings["records_sent_to_other_ranks"] = int(sum(send_list) - send_list[dist.get_rank(group)])
+        timings["records_sent_to_other_ranks"] = int(sum(send_list) - send_list[rank])
         timings["all_to_all_bytes_sent"] = int(sum(send_list)) * rec_bytes
         timings["all_to_all_bytes_received"] = int(sum(recv_list)) * rec_bytes
         timings["record_bytes"] = rec_bytes

@@ -252,6 +252,9 @@ class Engine:
         _lib.check(self.L.mdd_comm_init(self.ctx, buf, int(rank), int(world)), "mdd_comm_init")
         self.comm_rank, self.comm_world = int(rank), int(world)
 
+    def comm_destroy(self):
+        _lib.check(self.L.mdd_comm_destroy(self.ctx), "mdd_comm_destroy")
+
     def exchange_bands(self, tuples_s: torch.Tensor, meta_s: torch.Tensor, send_counts: torch.Tensor, rows: int):
         """band records grouped by owner (route) -> the records this rank owns; send_counts: int64 DEVICE tensor [world].
         Returns (tuples int32 [n*rows], meta int64 [n], send counts, recv counts (python lists))."""
