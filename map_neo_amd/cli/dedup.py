@@ -182,10 +182,9 @@ def run(args, engine_factory=None) -> dict:
                 s_ready = eng.signatures(padded(r["text"]), eng.to_device(r["offsets"]), args.num_perm, args.width,
                                          args.ngram_unit, args.seed, text_bytes=int(r["text"].size))
                 sig[eng.to_device(r["ready"])] = s_ready
-            if len(r["raw"]):                        # EN:31-40 for pure-ASCII documents, on the device
-                n_text, n_offs, flags = eng.normalize_en(padded(r["raw_text"]), eng.to_device(r["raw_offsets"]))
-                assert int(flags.sum().item()) == 0
-                s_raw = eng.signatures(n_text, n_offs, args.num_perm, args.width, args.ngram_unit, args.seed)
+            if len(r["raw"]):                        # EN:31-40 on the device (flagged documents: Python steps)
+                s_raw, _ = eng.signatures_en(padded(r["raw_text"]), eng.to_device(r["raw_offsets"]), args.num_perm,
+                                             args.width, args.ngram_unit, args.seed)
                 sig[eng.to_device(r["raw"])] = s_raw
             sigs.append(sig)
             cand_ids.extend(ids[i] for i in cand.tolist())

@@ -35,24 +35,9 @@ def build_parser():
 
 
 def _normalised_signatures(eng, text, offs, num_perm=128, width=13, seed=1):
-    """EN:31-40 + EN:56-64 for a packed corpus in HBM: ASCII documents are normalised on the device, the
-    others (all of them when ftfy is installed: it rewrites ASCII too) by the Python steps."""
-    import torch
-
-    from .. import hostio
-    from ..minhash import pack_texts
-    n = offs.numel() - 1
-    n_text, n_offs, flags = eng.normalize_en(text, offs)
-    sig = eng.signatures(n_text, n_offs, num_perm, width, "char", seed)
-    host = torch.arange(n, device=eng.device) if hostio._ftfy is not None else torch.nonzero(flags).flatten()
-    if host.numel():
-        o = offs.cpu().numpy()
-        docs = []
-        for d in host.cpu().tolist():
-            docs.append(hostio.normalize_text(text[int(o[d]):int(o[d + 1])].cpu().numpy().tobytes().decode("utf8")))
-        buf, ho = pack_texts(docs)
-        sig[host] = eng.signatures(eng.to_device(buf), eng.to_device(ho), num_perm, width, "char", seed)
-    return sig
+    """EN:31-40 + EN:56-64 for a packed corpus in HBM (Engine.signatures_en: device normalisation, Python steps
+    for the documents the device flags -- all of them when ftfy is installed)."""
+    return eng.signatures_en(text, offs, num_perm, width, "char", seed)[0]
 
 
 def run(args) -> dict:

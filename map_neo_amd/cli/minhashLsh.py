@@ -63,15 +63,20 @@ def build_parser() -> argparse.ArgumentParser:
                    help="who parses the shards in pass 1.  threads: no pickling of the packed text (about 20 %% faster on "
                         "ASCII corpora with libmdd_io.so), but lines that fall back to the Python steps (non-ASCII text "
                         "under EN normalisation) then serialise on the GIL; auto = threads when libmdd_io.so is available")
+    p.add_argument("--normalize_on", choices=["auto", "device", "host"], default="auto",
+                   help="where normalize_text (EN:31-40) runs.  device: the workers hand over the raw content and the GPU "
+                        "normalises it (non-ASCII text included; the few documents it cannot vouch for take the Python steps); "
+                        "host: the workers normalise (native code for ASCII lines, the Python steps for every non-ASCII line); "
+                        "auto = device unless ftfy is installed (ftfy rewrites text in ways only Python can)")
     return p
 
 
 def _parse_file(task):
     """pool worker, pass 1: (doc_ids of all rows, indices of candidate rows, packed text, offsets).
-    Native scanner + ASCII normaliser where it is sure, the Python steps elsewhere (hostio)."""
-    path, field = task
+    Native scanner (+ ASCII normaliser when the host normalises) where it is sure, the Python steps elsewhere (hostio)."""
+    path, field, host_norm = task
     from .. import hostio
-    r = hostio.read_jsonl_shard(path, field, "doc_id", normalize_en=True, on_error="skip")
+    r = hostio.read_jsonl_shard(path, field, "doc_id", normalize_en=host_norm, on_error="skip")
     if r["n_bad"]:
         print(f"{os.path.basename(path)}: {r['n_bad']} lines are not JSON objects and were skipped", file=sys.stderr)
     return path, r["ids"], r["cand"], r["text"], r["offsets"]
@@ -171,17 +176,26 @@ def minhashLsh(args) -> dict:
             # its buffers reach this process without pickling; the forked pool above serves the Python-heavy pass 2
             from multiprocessing.pool import ThreadPool
             tpool = ThreadPool(max(1, args.workers)) if (args.reader == "threads" or (args.reader == "auto" and hostio._io() is not None)) else None
-            parsed = (tpool or pool).imap(_parse_file, [(p, args.content_field_name) for p in files])
+            host_norm = args.normalize_on == "host" or (args.normalize_on == "auto" and hostio._ftfy is not None)
+            parsed = (tpool or pool).imap(_parse_file, [(p, args.content_field_name, host_norm) for p in files])
             eng = Engine(args.device)
-            sigs, cand_ids, n_rows = [], [], 0
+            sigs, cand_ids, n_rows, n_host_docs = [], [], 0, 0
             for path, ids, cand, text, offs in parsed:
                 n_rows += len(ids)
                 if len(cand):
                     buf = np.zeros(padded_size(text.size), dtype=np.uint8)
                     buf[: text.size] = text
-                    sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
-                                               args.ngram_unit, args.seed, text_bytes=int(text.size)))
+                    if host_norm:
+                        sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                                                   args.ngram_unit, args.seed, text_bytes=int(text.size)))
+                    else:
+                        s, nh = eng.signatures_en(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                                                  args.ngram_unit, args.seed)
+                        sigs.append(s)
+                        n_host_docs += nh
                     cand_ids.extend(ids[i] for i in cand.tolist())
+            if not host_norm:
+                print(f"normalised on the device; {n_host_docs} documents took the Python steps", file=sys.stderr)
             sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
             sig_h = as_u32(sig).reshape(len(cand_ids), args.num_perm)
             # the signatures are on disk before anything else happens to them (EN:128-129), so that a failure in a

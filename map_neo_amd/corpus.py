@@ -158,6 +158,10 @@ def _tokens(spec: CorpusSpec, d0: int, d1: int, device) -> Tuple[torch.Tensor, .
             qb = _lsr(_h(spec.seed + 31 + j, doc, 0), 33) % torch.clamp(nt, min=1)
             q, q2 = torch.minimum(qa, qb), torch.maximum(qa, qb)
             on = is_dup & (npair > j)
+            if spec.rate_idx is not None and (spec.rate_table == 0).any():
+                # a near-copy that drew the rate 0 is an EXACT copy: no insertions / deletions either
+                zero = torch.from_numpy(spec.rate_table == 0).to(device)[torch.from_numpy(spec.rate_idx[d0:d1].astype(np.int64)).to(device)]
+                on = on & ~zero[doc_local]
             shift = shift + (on & (pos >= q) & (pos < q2)).to(torch.int64)
             inserted = inserted | (on & (pos == q2) & (q2 > q))
         spos = torch.minimum(pos + shift, nt - 1)
@@ -216,11 +220,13 @@ def generate(spec: CorpusSpec, d0: int = 0, d1: Optional[int] = None, device="cp
     return text, offsets
 
 
-def generate_chunked(spec: CorpusSpec, device, docs_per_chunk: int = 32768):
-    """Whole corpus on `device`, generated chunk-wise to bound temporaries."""
+def generate_chunked(spec: CorpusSpec, device, docs_per_chunk: int = 32768, first: int = 0, last: Optional[int] = None):
+    """Documents [first, last) of the corpus (default: all of it) on `device`, generated chunk-wise to bound temporaries
+    (generate() holds ~100 bytes of temporaries per text byte)."""
+    last = spec.n_docs if last is None else min(last, spec.n_docs)
     texts, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=device)], 0
-    for d0 in range(0, spec.n_docs, docs_per_chunk):
-        d1 = min(spec.n_docs, d0 + docs_per_chunk)
+    for d0 in range(first, last, docs_per_chunk):
+        d1 = min(last, d0 + docs_per_chunk)
         t, o = generate(spec, d0, d1, device)
         nb = int(o[-1].item())
         texts.append(t[:nb])

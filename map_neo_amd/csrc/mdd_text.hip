@@ -1,6 +1,6 @@
-// EN text normalisation on the device for pure-ASCII documents.
+// EN text normalisation on the device.
 // Restates normalize_text, Matrix/english_data_clean_pipeline/dedup/Minhash_Lsh_Deduplication/
-// minhashLsh.py:31-40, on the inputs where it needs no Unicode tables:
+// minhashLsh.py:31-40.  Pure-ASCII stretches need no Unicode tables:
 //   ftfy.fix_text(normalization="NFC")  identity on clean ASCII (NFC never changes ASCII; with ftfy
 //                                       installed the host keeps doing this step, see hostio.py)
 //   .lower()                            A-Z -> a-z
@@ -8,11 +8,18 @@
 //   .strip()                            leading / trailing whitespace removed
 //   re.sub(r"\s+", " ")                 every remaining whitespace run becomes one space
 // ASCII whitespace as Python's str.isspace / re \s see it: 0x09-0x0D, 0x1C-0x1F, 0x20.
-// Documents holding any byte >= 0x80 are flagged and produce no output: the caller runs the
-// Python steps on exactly those.  One wave per document, 64 bytes per step (4 steps per load batch); the output position of
+// Round 3: 256-byte steps that hold a byte >= 0x80 take a table-driven path (mdd_unicode_tab.h, generated from the
+// interpreter's own unicodedata / str.lower / str.isspace by tools/gen_unicode_tables.py): utf-8 is validated and decoded,
+// every code point is looked up -- 1:1 lower case, Unicode whitespace (what str.strip / re's \s see), and a "cannot vouch"
+// flag for everything where the Python steps are not per-character (not NFC-inert: combining marks, composable or
+// decomposable characters; U+0130 and U+03A3, whose lower() is not 1:1 / context-free; unassigned code points; invalid
+// utf-8).  Only documents that hold a flagged code point are handed back (flag = 1, no output): the caller runs the
+// Python steps on exactly those, as it did for every non-ASCII document before.  (The byte-per-lane kernel for unaligned
+// text keeps flagging every non-ASCII document.)  One wave per document, 64 bytes per step (4 steps per load batch); the output position of
 // every byte comes from ballots + popcounts, so there is no scan and no LDS.  HBM-bound: the text
 // is read twice (count, write) and the normalised text written once.
 #include "mdd_common.h"
+#include "mdd_unicode_tab.h"
 
 namespace {
 using namespace mddi;
@@ -78,6 +85,87 @@ __global__ void __launch_bounds__(256) norm_en_kernel(const uint8_t* __restrict_
     }
 }
 
+// table entry of a code point >= 0x80 (mdd_unicode_tab.h): MDD_UNI_FALLBACK | MDD_UNI_SPACE | 21-bit (lower(c) - c)
+__device__ __forceinline__ uint32_t uni_entry(uint32_t cp) {
+    if (cp < MDD_UNI_LIMIT) return mdd_uni_blk[((uint32_t)mdd_uni_idx[cp >> 8] << 8) | (cp & 255u)];
+    for (int r = 0; r < MDD_UNI_NRANGES; r++)
+        if (cp - mdd_uni_hi[r][0] <= mdd_uni_hi[r][1] - mdd_uni_hi[r][0]) return 0u;  // uncased, not whitespace
+    return MDD_UNI_FALLBACK;
+}
+// utf-8 of cp as little-endian bytes of the result, length in len (1..4)
+__device__ __forceinline__ uint32_t utf8_encode(uint32_t cp, uint32_t& len) {
+    if (cp < 0x80u) {
+        len = 1;
+        return cp;
+    }
+    if (cp < 0x800u) {
+        len = 2;
+        return (0xC0u | (cp >> 6)) | ((0x80u | (cp & 0x3Fu)) << 8);
+    }
+    if (cp < 0x10000u) {
+        len = 3;
+        return (0xE0u | (cp >> 12)) | ((0x80u | ((cp >> 6) & 0x3Fu)) << 8) | ((0x80u | (cp & 0x3Fu)) << 16);
+    }
+    len = 4;
+    return (0xF0u | (cp >> 18)) | ((0x80u | ((cp >> 12) & 0x3Fu)) << 8) | ((0x80u | ((cp >> 6) & 0x3Fu)) << 16) | ((0x80u | (cp & 0x3Fu)) << 24);
+}
+
+// One lane's 4 bytes of a step that holds non-ASCII bytes.  v8 = the lane's dword and the one after it (a code point
+// that starts in this lane is emitted by this lane, its continuation bytes may lie in the next one); inb = bit k set when
+// byte k belongs to the document; p = text position of byte 0; e = end of the document.  Results: Wm / Nm = bit k set
+// when a kept whitespace / non-whitespace code point STARTS at byte k; enc[k] / len[k] its lower-cased utf-8 (Nm only);
+// bal += continuation bytes the lane's lead bytes own - continuation bytes the lane holds (0 over a valid document).
+// Returns false when the document must go to the host (invalid utf-8 or a flagged code point).
+__device__ __forceinline__ bool classify_unicode(uint64_t v8, uint32_t inb, uint64_t p, uint64_t e, uint32_t& Wm, uint32_t& Nm,
+                                                 uint32_t (&enc)[4], uint32_t (&len)[4], int32_t& bal) {
+    bool ok_all = true;
+    Wm = Nm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        len[k] = 0;
+        enc[k] = 0;
+        if (!((inb >> k) & 1u)) continue;
+        const uint32_t v = (uint32_t)(v8 >> (8 * k));
+        const uint32_t b0 = v & 0xFFu;
+        if (b0 < 0x80u) {
+            if (is_punct(b0)) continue;
+            if (is_space(b0)) {
+                Wm |= 1u << k;
+            } else {
+                Nm |= 1u << k;
+                enc[k] = (b0 - 65u <= 25u) ? b0 + 32u : b0;
+                len[k] = 1;
+            }
+        } else if ((b0 & 0xC0u) == 0x80u) {
+            bal -= 1;
+        } else {
+            const uint32_t L = b0 >= 0xF0u ? 4u : (b0 >= 0xE0u ? 3u : 2u);
+            const uint32_t b1 = (v >> 8) & 0xFFu, b2 = (v >> 16) & 0xFFu, b3 = v >> 24;
+            bool ok = (p + k + L <= e) && b0 >= 0xC2u && b0 <= 0xF4u && (b1 & 0xC0u) == 0x80u && (L < 3u || (b2 & 0xC0u) == 0x80u) &&
+                      (L < 4u || (b3 & 0xC0u) == 0x80u);
+            const uint32_t cp = L == 2u   ? ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu)
+                                : L == 3u ? ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu)
+                                          : ((b0 & 7u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+            ok = ok && (L == 2u || (L == 3u && cp >= 0x800u && cp - 0xD800u > 0x7FFu) || (L == 4u && cp - 0x10000u <= 0xFFFFFu));
+            if (!ok) {
+                ok_all = false;
+                continue;
+            }
+            bal += (int32_t)L - 1;
+            const uint32_t ent = uni_entry(cp);
+            if (ent & MDD_UNI_FALLBACK) {
+                ok_all = false;
+            } else if (ent & MDD_UNI_SPACE) {
+                Wm |= 1u << k;
+            } else {
+                Nm |= 1u << k;
+                enc[k] = utf8_encode((cp + ent) & 0x1FFFFFu, len[k]);
+            }
+        }
+    }
+    return ok_all;
+}
+
 // Count and write passes, dword per lane (text 4-byte aligned): a lane owns 4 consecutive bytes, a wave step covers 256.
 // The byte classes come from SWAR range tests on the whole dword (bytes are < 0x80 in every document that
 // survives, so x + (128 - lo) and x + (127 - hi) never carry into the neighbour byte; bit 7 of a byte then
@@ -109,6 +197,7 @@ __global__ void __launch_bounds__(256) norm_en4_kernel(const uint8_t* __restrict
         uint64_t done = WRITE ? out_offs[d] : 0;      // WRITE: next output position of the wave (wave-uniform)
         uint32_t cnt = 0;                             // count pass: this lane's bytes, summed once per document
         bool carry_ws = false, carry_seen = false, bad = false;  // wave-uniform carries between steps
+        int32_t bal = 0;  // continuation bytes owned by lead bytes - continuation bytes seen: 0 over valid utf-8
         for (uint64_t wi = w0; wi < w1 && !bad; wi += 128) {
             uint32_t ww[2];  // two independent loads in flight
 #pragma unroll
@@ -126,9 +215,59 @@ __global__ void __launch_bounds__(256) norm_en4_kernel(const uint8_t* __restrict
                 for (int k = 0; k < 4; k++)
                     if (i < w1 && p + k >= b && p + k < e) in |= 0x80u << (8 * k);
                 const uint32_t w = ww[j];
-                if (!WRITE && __ballot((w & in) != 0u)) {  // a byte >= 0x80: the document goes to the Python steps
-                    bad = true;
-                    break;
+                if (__ballot((w & in) != 0u)) {  // a byte >= 0x80 in this step: the table-driven path (same carries, same counters)
+                    const uint32_t nx = i < w1 ? tw[i + 1] : 0u;  // the dword after the lane's (inside the text's padding at the end)
+                    const uint32_t inb = ((in >> 7) & 1u) | ((in >> 14) & 2u) | ((in >> 21) & 4u) | ((in >> 28) & 8u);
+                    uint32_t Wm, Nm, enc[4], len[4];
+                    const bool okl = classify_unicode((uint64_t)w | ((uint64_t)nx << 32), inb, p, e, Wm, Nm, enc, len, bal);
+                    if (__ballot(!okl)) {  // (cannot happen in the write pass: flagged documents are skipped)
+                        bad = true;
+                        break;
+                    }
+                    const uint32_t Km = Wm | Nm;
+                    const bool has_k = Km != 0u, has_n = Nm != 0u;
+                    const bool last_ws = has_k && ((Wm >> (31u - (uint32_t)__builtin_clz(Km))) & 1u);
+                    const uint64_t BK = __ballot(has_k), BW = __ballot(last_ws), BN = __ballot(has_n);
+                    const uint64_t pk = BK & lt;
+                    bool pw = pk ? ((BW >> (63 - __builtin_clzll(pk))) & 1) : carry_ws;
+                    bool sn = carry_seen || (BN & lt);
+                    uint32_t c = 0, spm = 0;  // bytes this lane emits; bit k: a space goes before the code point at byte k
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if ((Nm >> k) & 1u) {
+                            if (pw && sn) {
+                                spm |= 1u << k;
+                                c++;
+                            }
+                            c += len[k];
+                            sn = true;
+                            pw = false;
+                        } else if ((Wm >> k) & 1u) {
+                            pw = true;
+                        }
+                    }
+                    if (!WRITE) {
+                        cnt += c;
+                    } else {  // c <= 20: five count planes
+                        const uint64_t c0 = __ballot(c & 1u), c1 = __ballot(c & 2u), c2 = __ballot(c & 4u), c3 = __ballot(c & 8u), c4 = __ballot(c & 16u);
+                        uint64_t pos = done + __builtin_popcountll(c0 & lt) + 2 * __builtin_popcountll(c1 & lt) + 4 * __builtin_popcountll(c2 & lt) +
+                                       8 * __builtin_popcountll(c3 & lt) + 16 * __builtin_popcountll(c4 & lt);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (!((Nm >> k) & 1u)) continue;
+                            if ((spm >> k) & 1u) {
+                                if (pos < out_cap) out_text[pos] = ' ';
+                                pos++;
+                            }
+                            for (uint32_t q = 0; q < len[k]; q++, pos++)
+                                if (pos < out_cap) out_text[pos] = (uint8_t)(enc[k] >> (8 * q));  // out_offsets are the caller's: stay inside out_text
+                        }
+                        done += __builtin_popcountll(c0) + 2 * __builtin_popcountll(c1) + 4 * __builtin_popcountll(c2) + 8 * __builtin_popcountll(c3) +
+                                16 * __builtin_popcountll(c4);
+                    }
+                    if (BK) carry_ws = (BW >> (63 - __builtin_clzll(BK))) & 1;
+                    carry_seen = carry_seen || BN;
+                    continue;
                 }
                 const uint32_t x = w & 0x7F7F7F7Fu;
                 const uint32_t punct = swar_in_range(x, 33, 47) | swar_in_range(x, 58, 64) | swar_in_range(x, 91, 96) |
@@ -193,7 +332,11 @@ __global__ void __launch_bounds__(256) norm_en4_kernel(const uint8_t* __restrict
         if (!WRITE) {
             uint32_t tot = cnt;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+            for (int o = 32; o >= 1; o >>= 1) {
+                tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+                bal += __shfl_xor(bal, o, 64);
+            }
+            bad = bad || bal != 0;  // a continuation byte no lead byte owns
             if (lane == 0) {
                 out_len[d] = bad ? 0 : tot;
                 non_ascii[d] = bad;

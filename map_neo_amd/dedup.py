@@ -89,6 +89,36 @@ def dedup_local(be, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = N
     return cluster_local(be, sig, bands, rows, key_bits, want_buckets, timer, min_jaccard)
 
 
+def signatures_streamed(be, blocks, n_docs: int, num_perm=NUM_PERM, width: int = WIDTH, unit: str = "char", seed: int = SEED,
+                        on_block=None):
+    """Signatures of a corpus that does not (have to) fit in HBM as text: `blocks` yields (text, offsets, text_bytes) of
+    consecutive document ranges (packed device tensors, as for Engine.signatures); every block is hashed into its rows of
+    ONE resident signature matrix and may then be dropped -- at 100 M documents the text is ~220 GB, the signatures 51 GB.
+    num_perm may be a tuple: several matrices from one pass over the text (band sweeps with different K).
+    on_block(first_doc, text, offsets, text_bytes, ms) is called after each block (ms: kernel time by events).
+    Returns the int32 matrix [n_docs, K] (a dict K -> matrix when num_perm is a tuple)."""
+    many = isinstance(num_perm, (tuple, list))
+    Ks = list(num_perm) if many else [num_perm]
+    sigs = {K: torch.empty((n_docs, K), dtype=torch.int32, device=be.device) for K in Ks}
+    d0 = 0
+    for text, offs, nbytes in blocks:
+        nd = offs.numel() - 1
+        if d0 + nd > n_docs:
+            raise ValueError("signatures_streamed: the blocks hold more than n_docs documents")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for K in Ks:
+            be.signatures(text, offs, K, width, unit, seed, text_bytes=nbytes, out=sigs[K][d0:d0 + nd])
+        e1.record()
+        if on_block is not None:
+            e1.synchronize()
+            on_block(d0, text, offs, nbytes, e0.elapsed_time(e1))
+        d0 += nd
+    if d0 != n_docs:
+        raise ValueError("signatures_streamed: the blocks hold %d documents, expected %d" % (d0, n_docs))
+    return sigs if many else sigs[Ks[0]]
+
+
 # RCCL on this stack silently drops the tail of an all_to_all_single message beyond 1 GiB (measured with one rank:
 # everything past the first half of a 1 GiB + 8 KiB message arrives untouched, tools/diag_a2a.py), so no single
 # collective call here moves more than COLLECTIVE_BYTES (half the observed limit) in total; larger exchanges run in rounds.

@@ -342,11 +342,11 @@ def read_parquet_shard(path: str, content_field: str, id_field=None, normalize_e
                  non-null, valid utf-8 string; EN:124, ZH-1:52-54)
       text, offsets        packed utf-8 of the documents that are READY to hash
       ready      int64, position in `cand` of each of those documents
-      raw_text, raw_offsets, raw   pure-ASCII documents still to be normalised (EN:31-40) --
-                 on the device with Engine.normalize_en -- and their positions in `cand`
-    Without normalize_en every document is ready.  With it, documents holding non-ASCII bytes
-    (or all documents when ftfy is installed, which rewrites ASCII text too) are normalised here
-    by `normalize_text`; the rest is left to the device."""
+      raw_text, raw_offsets, raw   documents still to be normalised (EN:31-40) -- on the device with
+                 Engine.signatures_en -- and their positions in `cand`
+    Without normalize_en every document is ready.  With it everything is left to the device, unless
+    ftfy is installed (it rewrites ASCII text too): then all documents are normalised here by
+    `normalize_text`."""
     import numpy as np
     import pyarrow as pa
     import pyarrow.parquet as pq
@@ -402,8 +402,9 @@ def read_parquet_shard(path: str, content_field: str, id_field=None, normalize_e
     if _ftfy is not None:
         host = np.arange(nd, dtype=np.int64)
     else:
-        hi = np.flatnonzero(data >= 0x80).astype(np.uint64)
-        host = np.unique(np.searchsorted(offs, hi, side="right") - 1).astype(np.int64)
+        # the device normalises non-ASCII documents too (generated Unicode table) and hands back the few it cannot
+        # vouch for (Engine.signatures_en), so nothing is normalised here
+        host = np.zeros(0, dtype=np.int64)
     pieces = [normalize_text(data[int(offs[k]):int(offs[k + 1])].tobytes().decode("utf8")).encode("utf8") for k in host.tolist()]
     t_off = np.zeros(len(pieces) + 1, dtype=np.uint64)
     if pieces:

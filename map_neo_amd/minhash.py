@@ -474,10 +474,36 @@ class Engine:
         out_offs = torch.cat([out_offs_all[:-1][docs], out_offs_all[-1:]])
         return out_text, out_offs, docs
 
+    def signatures_en(self, text: torch.Tensor, offsets: torch.Tensor, num_perm: int = NUM_PERM, width: int = WIDTH,
+                      unit: str = "char", seed: int = SEED):
+        """generate_minhash_value after normalize_text (EN:31-40 + EN:56-64) for RAW documents in HBM: normalised on
+        the device (normalize_en), hashed, and the few documents the device cannot vouch for (flags == 1: combining
+        marks, composable / decomposable characters, U+0130, U+03A3, unassigned code points, invalid utf-8) -- all
+        documents when ftfy is installed, it rewrites ASCII text too -- go through the Python steps
+        (hostio.normalize_text) and are hashed in a second call.  Returns (sig int32 [n, K], number of host documents)."""
+        from . import hostio
+        n = offsets.numel() - 1
+        n_text, n_offs, flags = self.normalize_en(text, offsets)
+        sig = self.signatures(n_text, n_offs, num_perm, width, unit, seed)
+        host = torch.arange(n, device=self.device) if hostio._ftfy is not None else torch.nonzero(flags).flatten()
+        if host.numel():
+            o = offsets.cpu().numpy()
+            docs = []
+            for d in host.cpu().tolist():
+                raw = text[int(o[d]):int(o[d + 1])].cpu().numpy().tobytes()
+                try:
+                    docs.append(hostio.normalize_text(raw.decode("utf8")))
+                except UnicodeDecodeError:      # not a str the reference could have held: hashed as the empty document
+                    docs.append("")
+            buf, ho = pack_texts(docs)
+            sig[host] = self.signatures(self.to_device(buf), self.to_device(ho), num_perm, width, unit, seed)
+        return sig, int(host.numel())
+
     def normalize_en(self, text: torch.Tensor, offsets: torch.Tensor):
-        """EN:31-40 on the pure-ASCII documents of a packed batch, on the device.  Returns
-        (out_text uint8 [padded], out_offsets int64 [n+1], non_ascii uint8 [n]); documents with
-        non_ascii[d] == 1 have zero length in the output and must be normalised by the caller."""
+        """EN:31-40 on a packed batch, on the device (ASCII stretches by byte classes, everything else through the
+        generated Unicode table, csrc/mdd_unicode_tab.h).  Returns (out_text uint8 [padded], out_offsets int64 [n+1],
+        flags uint8 [n]); documents with flags[d] == 1 hold a code point the device cannot vouch for (see
+        signatures_en): they have zero length in the output and must be normalised by the caller."""
         n = offsets.numel() - 1
         out_len = torch.zeros(max(n, 0), dtype=torch.int64, device=self.device)
         flags = torch.zeros(max(n, 0), dtype=torch.uint8, device=self.device)

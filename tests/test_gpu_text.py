@@ -1,4 +1,4 @@
-"""GPU suite: EN normalisation of pure-ASCII documents on the device
+"""GPU suite: EN normalisation on the device (ASCII by byte classes, everything else table-driven)
 against the ORACLE's statement of EN:31-40 (oracle.ref_py.normalize_text; ftfy is absent here: NFC only)."""
 import numpy as np
 import pytest
@@ -34,11 +34,121 @@ def test_normalize_en_matches_python(engine):
         assert g == R.normalize_text(d.decode("ascii")).encode("ascii"), d
 
 
-def test_non_ascii_documents_are_flagged_not_touched(engine):
-    docs = ["Plain ASCII, here.", "naïve café", "", "中文 文档", "x" * 200 + "é", "Tail  OK!"]
+def _flagged_by_generator():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_unicode_tables as G
+    maybe = G.maybe_set()
+    return lambda c: G.flagged(c, maybe)
+
+
+def test_non_ascii_documents_known_cases(engine):
+    """round 3: non-ASCII documents are normalised on the device through the generated Unicode table; only documents
+    holding a code point whose Python steps are not per-character come back flagged (and untouched)"""
+    ok = ["Plain ASCII, here.", "na\u00efve caf\u00e9", "", "\u4e2d\u6587 \u6587\u6863", "x" * 200 + "\u00e9", "Tail  OK!",
+          "\u201cCurly\u201d \u2018quotes\u2019 \u2013 and\u2014dashes\u2026", "A\u00a0B\u3000C\u0085D\u2028E\u2029F\u202fG\u205fH\u1680I",
+          "\u00a0\u3000 lead and trail \u2009\u200a", "\u00c9COLE \u00dcBER STRA\u1e9eE \u0410\u0411\u0412 \u0391\u0392\u0393",
+          "emoji \U0001f600!\U0001f680 astral \U00010400\U00010401 deseret", "\U00020000\U0002a6dd cjk ext b", "\u023a\u023e grow on lower",
+          "\uff21\uff22 fullwidth", "\u2160\u2161 roman", "\u24b6\u24b7 circled", "\ua78d\ua7aa \u13a0\u13a1 far lower"]
+    flagged = ["e\u0301 combining", "\u0130stanbul", "\u039f\u0394\u039f\u03a3 sigma", "\u212b angstrom", "\u2000 en quad", "\u1100\u1161 jamo",
+               "\u0378 unassigned", "\u0345 ypogegrammeni", "ok ok ok " * 40 + "\u0301"]
+    docs = ok + flagged
     got, flags = _run(engine, docs)
-    assert flags.tolist() == [0, 1, 0, 1, 1, 0]
-    assert got == [b"plain ascii here", b"", b"", b"", b"", b"tail ok"]
+    assert flags.tolist() == [0] * len(ok) + [1] * len(flagged)
+    for d, g in zip(ok, got):
+        assert g == R.normalize_text(d).encode("utf8"), d
+    assert all(g == b"" for g in got[len(ok):])
+
+
+def test_invalid_utf8_is_flagged(engine):
+    bad = [b"abc\x80def", b"\xc3", b"tail \xe4\xb8", b"\xc0\x80 overlong", b"\xe0\x80\x80 overlong3", b"\xf0\x80\x80\x80 overlong4",
+           b"\xed\xa0\x80 surrogate", b"\xf4\x90\x80\x80 beyond", b"\xf5\x80\x80\x80", b"\xff", b"\xc3\x28", b"\xe4\xb8\x28x",
+           b"a" * 255 + b"\xc3", b"a" * 253 + b"\xf0\x9f\x98", b"\x80" + b"a" * 300, b"\xe4\xb8\xad\xad"]
+    good = [b"fine", "caf\u00e9".encode(), b"a" * 255 + "\u00e9".encode(), b"a" * 253 + "\U0001f600".encode()]
+    # a lead byte at the end of one document whose continuation bytes open the next: both are invalid on their own
+    split = ["\u4e2d".encode()[:1], "\u4e2d".encode()[1:] + b" rest"]
+    docs = bad + good + split
+    got, flags = _run(engine, docs)
+    assert flags.tolist() == [1] * len(bad) + [0] * len(good) + [1, 1]
+    for d, g in zip(good, got[len(bad):len(bad) + len(good)]):
+        assert g == R.normalize_text(d.decode("utf8")).encode("utf8")
+
+
+def test_random_unicode_documents_vs_oracle(engine):
+    """random BMP + astral documents: unflagged documents equal the oracle's normalize_text, and a document is flagged
+    exactly when it holds a code point the table generator flags (no over-flagging)"""
+    is_flagged = _flagged_by_generator()
+    rng = np.random.Generator(np.random.PCG64(21))
+    pools = [np.arange(0x20, 0x7f), np.arange(0xa0, 0x250), np.arange(0x370, 0x530), np.arange(0x2000, 0x2070), np.arange(0x3000, 0x3100),
+             np.arange(0x4e00, 0x4f00), np.arange(0xac00, 0xac80), np.arange(0x1f600, 0x1f650), np.arange(0x10400, 0x10450),
+             np.arange(0x1e900, 0x1e944), np.arange(0xff00, 0xff60), np.array([9, 10, 13, 0x85, 0xa0, 0x1680, 0x2028, 0x3000, 0x202f]),
+             np.arange(0x300, 0x310), np.arange(0x1100, 0x1200), np.arange(0x2f800, 0x2f810), np.arange(0xe0100, 0xe0110), np.arange(0x1d00, 0x1e00)]
+    docs = []
+    for _ in range(4000):
+        n = int(rng.integers(0, 300))
+        k = rng.integers(1, 5)
+        use = rng.choice(len(pools) - 5 if rng.random() < 0.8 else len(pools), k)     # 80 %: pools without combining marks / jamo / ...
+        w = rng.random(len(use)) + (use == 0) * 3.0                                    # mostly ASCII with islands of the rest
+        which = rng.choice(len(use), n, p=w / w.sum())
+        cps = [int(rng.choice(pools[use[j]])) for j in which]
+        docs.append("".join(chr(c) for c in cps if not 0xd800 <= c < 0xe000))
+    got, flags = _run(engine, docs)
+    n_flag = 0
+    for d, g, f in zip(docs, got, flags.tolist()):
+        want_flag = any(is_flagged(ord(ch)) for ch in d)
+        assert bool(f) == want_flag, [hex(ord(ch)) for ch in d if is_flagged(ord(ch))]
+        if f:
+            n_flag += 1
+            assert g == b""
+        else:
+            assert g == R.normalize_text(d).encode("utf8"), d
+    assert 100 < n_flag < 3000
+
+
+def test_code_points_across_lane_and_step_boundaries(engine):
+    """multi-byte code points at every position of a 256-byte step (lane and step straddles), documents at every alignment"""
+    docs = []
+    for ch in ["\u00e9", "\u4e2d", "\U0001f600", "\u00a0", "\u3000", "\u00c9"]:
+        for k in range(0, 264):
+            docs.append("a" * k + ch + "B c" + ch + ch + " ." + ch)
+    got, flags = _run(engine, docs)
+    assert not flags.any()
+    for d, g in zip(docs, got):
+        assert g == R.normalize_text(d).encode("utf8"), d
+
+
+def test_web_english_with_latin1_rarely_falls_back(engine):
+    """corpus text with Latin-1 punctuation / accents / typographic quotes injected into half of the documents: fewer
+    than 1 % of the documents go back to the host, and signatures_en hashes all of them right"""
+    import torch
+    from map_neo_amd import corpus
+    from oracle import ref_c as RC
+    spec = corpus.CorpusSpec(3000, 1500, seed=5, lang="en")
+    text, offs = corpus.generate(spec, device="cpu")
+    t, o = text.numpy(), offs.numpy()
+    rng = np.random.Generator(np.random.PCG64(6))
+    inject = ["\u2019", "\u201c", "\u201d", "\u2014", "\u2013", "\u00e9", "\u00e8", "\u00fc", "\u00a0", "\u2026", "\u00c9", "\u00df", "\u00b7", "\u00ab", "\u00bb"]
+    docs = []
+    for d in range(spec.n_docs):
+        sdoc = bytes(t[o[d]:o[d + 1]]).decode("ascii")
+        if d % 2 == 0 and len(sdoc) > 4:
+            cs = list(sdoc)
+            for pos in sorted(rng.integers(0, len(cs), max(1, len(cs) // 60)).tolist(), reverse=True):
+                cs.insert(pos, inject[int(rng.integers(0, len(inject)))])
+            if d % 200 == 0:
+                cs.insert(len(cs) // 2, "e\u0301")          # a decomposed accent: the one kind that must go back
+            sdoc = "".join(cs).title() if d % 4 == 0 else "".join(cs)
+        docs.append(sdoc)
+    buf, offs2 = pack_texts(docs)
+    tt, oo = engine.to_device(buf), engine.to_device(offs2)
+    _, _, flags = engine.normalize_en(tt, oo)
+    n_flag = int(flags.sum().item())
+    assert n_flag == len([d for d in range(spec.n_docs) if d % 200 == 0 and len(docs[d]) > 4]) and n_flag < 0.01 * spec.n_docs
+    sig, n_host = engine.signatures_en(tt, oo)
+    assert n_host == n_flag
+    nbuf, noffs = pack_texts([R.normalize_text(d) for d in docs])
+    assert (sig.cpu().numpy().view(np.uint32) == RC.signatures(nbuf, noffs)).all()
 
 
 def test_long_document_and_full_pipeline_equivalence(engine):
