@@ -37,7 +37,13 @@ extern "C" {
 #define MDD_ERR_UNSUPPORTED (-3) /* parameter combination this build does not implement */
 
 #define MDD_UNIT_CHAR 0 /* shingle unit = Unicode code point (EN:61, ZH-1:27: nltk.ngrams over a str) */
-#define MDD_UNIT_WORD 1 /* shingle unit = space-separated token (BASELINE.json config 1; extension) */
+#define MDD_UNIT_WORD 1 /* shingle unit = space-separated token (BASELINE.json config 1; an extension: the reference has
+                         * no word unit, so its parity is unpinned).  DEFINITION: tokens are maximal runs of bytes other than
+                         * 0x20, and a shingle is the TEXT SPAN from the first byte of its first token to the last byte of its
+                         * last token (no copy of the tokens is made).  On single-space-normalised text (what EN:31-40
+                         * produces) that is exactly " ".join(tokens[i:i+width]), i.e. nltk.ngrams over text.split(" ");
+                         * on text with runs of spaces the run stays inside the shingle.  Normalise first (--normalize en)
+                         * when the nltk-equivalent is wanted. */
 
 #define MDD_TEXT_PAD 128 /* bytes the text allocation must extend past text_bytes (kernels load unclamped) */
 #define MDD_MAX_PERM 256

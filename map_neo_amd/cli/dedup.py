@@ -51,7 +51,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--min_jaccard", type=float, default=None,
                    help="extension (the reference has no such step): drop candidate pairs whose signatures agree on fewer than "
-                        "ceil(min_jaccard * num_perm) components before the union-find; one-GPU path only")
+                        "ceil(min_jaccard * num_perm) components before the union-find; one-GPU path only.  Only the STAR edges of a bucket "
+                        "are checked (each document against the smallest document of its bucket), not all pairs: two documents "
+                        "that are similar to each other but not to that document are split, unlike pairwise LSH verification")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
     p.add_argument("--checkpoint_dir", default=None,
@@ -128,17 +130,17 @@ def run(args, engine_factory=None) -> dict:
         os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.time()
     n_workers = max(1, args.workers // world)
+    ckpt_dir, resume = getattr(args, "checkpoint_dir", None), getattr(args, "resume_from", None)
+    if (ckpt_dir or resume) and distributed:           # flags are validated BEFORE the worker pool exists
+        raise SystemExit("--checkpoint_dir / --resume_from: single-process runs only")
+    if resume and not ckpt_dir:
+        raise SystemExit("--resume_from needs --checkpoint_dir")
     if files and all(f.lower().endswith((".parquet", ".pq")) for f in files):
         # Arrow decodes without the GIL and hands its buffers over without a copy: threads, not processes
         from multiprocessing.pool import ThreadPool
         pool = ThreadPool(n_workers)
     else:
         pool = mp.get_context("fork").Pool(n_workers)                      # forked before this process touches the GPU
-    ckpt_dir, resume = getattr(args, "checkpoint_dir", None), getattr(args, "resume_from", None)
-    if (ckpt_dir or resume) and distributed:
-        raise SystemExit("--checkpoint_dir / --resume_from: single-process runs only")
-    if resume and not ckpt_dir:
-        raise SystemExit("--resume_from needs --checkpoint_dir")
     try:
         parsed = pool.imap(_parse_shard, [(p, args.id_field, args.content_field, args.normalize) for p in ([] if resume else files)])
         import torch
@@ -191,7 +193,7 @@ def run(args, engine_factory=None) -> dict:
         t1 = time.time()
         state = None
         if resume:
-            state = ckpt.load(ckpt_dir, resume, ckpt.params_of(args))
+            state = ckpt.load(ckpt_dir, resume, ckpt.params_of(args), args.input_dir)
             cand_ids = state["doc_ids"]
             all_ids, any_synth = state["manifest"]["extra"]["all_ids"], state["manifest"]["extra"]["any_synth"]
         n = len(cand_ids)
@@ -199,7 +201,7 @@ def run(args, engine_factory=None) -> dict:
             sig = eng.to_device(state["signatures"].reshape(-1)).view(n, args.num_perm) if resume == "signatures" else None
         else:
             sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
-        ck_extra = {"all_ids": all_ids, "any_synth": any_synth}
+        ck_extra = {"all_ids": all_ids, "any_synth": any_synth, "input_dir": os.path.abspath(args.input_dir)}
         if ckpt_dir and not resume:
             ckpt.save(ckpt_dir, ckpt.params_of(args), cand_ids, signatures=as_u32(sig).reshape(n, args.num_perm), extra=ck_extra)
         if not distributed:

@@ -166,7 +166,7 @@ def minhashLsh(args) -> dict:
         from ..minhash import Engine, as_u32, padded_size
         sig_h = edges = labels = None
         if resume:
-            state = ckpt.load(args.inter_dir, resume, params)
+            state = ckpt.load(args.inter_dir, resume, params, args.input_dir)
             cand_ids, n_rows = state["doc_ids"], state["manifest"]["extra"].get("n_rows")
             sig_h, edges, labels = state.get("signatures"), state.get("edges"), state.get("labels")
             eng = Engine(args.device)

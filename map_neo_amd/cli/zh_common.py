@@ -81,6 +81,11 @@ def copy_without_lines(src: str, dst: str, drop) -> None:
         import gzip
         data = gzip.decompress(data)
         opener = gzip.open
+    # ZH-5:9-13 reads and writes in TEXT mode: "\r\n" and a lone "\r" end a line on input and every line goes out with
+    # "\n" (universal newlines).  Identity on "\n"-only files; otherwise the same translation is applied here, so line
+    # indices and output bytes are the reference's.
+    if b"\r" in data:
+        data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
     with opener(dst, "wb") as fw:
         if not drop:
             fw.write(data)
@@ -101,8 +106,29 @@ def write_pickle(path: str, obj) -> None:
         pickle.dump(obj, f)
 
 
+class _PlainUnpickler(pickle.Unpickler):
+    """The artifacts of these commands (and of the reference scripts) hold nothing but list / dict / set / tuple / str /
+    bytes / int: any other global a pickle asks for -- which is how a pickle runs code on load -- is refused."""
+
+    _ALLOWED = {(m, n) for m in ("builtins", "__builtin__") for n in ("list", "dict", "set", "frozenset", "tuple", "str", "bytes", "bytearray", "int")}
+
+    @staticmethod
+    def _latin1(text, encoding="latin1"):       # how protocols <= 2 spell a bytes object: _codecs.encode(str, "latin1")
+        if encoding != "latin1" or not isinstance(text, str):
+            raise pickle.UnpicklingError("unexpected _codecs.encode call in a dedup artifact")
+        return text.encode("latin1")
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        if (module, name) == ("_codecs", "encode"):
+            return self._latin1
+        raise pickle.UnpicklingError("refusing to load %s.%s from a dedup artifact (only plain containers are expected)" % (module, name))
+
+
 def read_own_pickle(path: str):
-    """Artifacts written by these commands (or by the reference scripts run by the same user).
-    Pickle executes code on load: only point this at files you produced."""
+    """Artifacts written by these commands or by the reference scripts (band lists ZH-1:58-61, the component triple
+    ZH-3:55-59, line-index sets ZH-4:28-31): plain containers only, loaded with an Unpickler that resolves no other
+    global, so a crafted file cannot execute anything."""
     with open(path, "rb") as f:
-        return pickle.load(f)
+        return _PlainUnpickler(f).load()

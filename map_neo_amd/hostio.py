@@ -54,9 +54,12 @@ def shard_output_names(paths, suffix: str = ".jsonl.gz"):
 
 
 def open_text(path: str, mode: str = "rt"):
+    """Text-mode READS use universal newlines like the reference's own `open(path, 'r')` (ZH-1:40, ZH-5:9) and Spark's
+    line reader (EN:120): "\n", "\r\n" and a lone "\r" all end a line.  Writes never translate."""
+    nl = None if "r" in mode else "\n"
     if path.endswith(".gz"):
-        return gzip.open(path, mode, encoding="utf8", newline="\n") if "t" in mode else gzip.open(path, mode)
-    return open(path, mode, encoding="utf8", newline="\n") if "t" in mode else open(path, mode)
+        return gzip.open(path, mode, encoding="utf8", newline=nl) if "t" in mode else gzip.open(path, mode)
+    return open(path, mode, encoding="utf8", newline=nl) if "t" in mode else open(path, mode)
 
 
 def iter_lines(path: str) -> Iterator[str]:
@@ -276,6 +279,12 @@ def read_jsonl_shard(path: str, content_field: str, id_field=None, normalize_en:
         text = arr("text", np.uint8, int(offs[-1]) if nd else 0)
     finally:
         L.mdd_io_free(h)
+    # The reference iterates its shards in TEXT mode (EN: Spark's line reader; ZH-1:40-42 `for idx, line in enumerate(f)`):
+    # a lone "\r" ends a line there.  The native scanner numbers lines by "\n" alone -- identical for "\n" and "\r\n"
+    # files ("\r" before "\n" is JSON whitespace); a shard with a lone "\r" takes the Python path, whose text-mode
+    # iteration is the reference's.
+    if raw.count(b"\r") != raw.count(b"\r\n"):
+        return read_jsonl_shard(path, content_field, id_field, normalize_en, on_error, use_native=False)
 
     ids = [None] * n
     for i in np.flatnonzero(idk == 1).tolist():

@@ -442,11 +442,11 @@ class Engine:
                 _lib.check(self.L.mdd_substr_mark_sorted(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
                                                          _ptr(ent_a), _ptr(ent_b), cap, _ptr(d1), _ptr(ws), ws.numel(), _ptr(dup)),
                            "mdd_substr_mark_sorted")
-            table = (ent_a, ent_b, d1, ws)
             if os.environ.get("MDD_LEAF_PROF"):      # profiling builds (-DMDD_LEAF_PROF): cycles per leaf-kernel phase
                 torch.cuda.synchronize(self.device)
                 base = (2048 + 1) + 2048 + (2 ** 22 + 1) + 2 ** 22 + 1024 + 2 ** 21
                 self.last_leaf_prof = ws[base + 1: base + 6].tolist()
+            del ent_a, ent_b, d1, ws        # the workspace (most of the free HBM) goes back before the outputs are allocated
         else:
             n_parts = max(1, -(-(16 * n_win) // max(1, table_bytes)))
             slots = 2 * n_win if n_parts == 1 else int(2.2 * n_win / n_parts) + 4096      # hash partitions are only nearly equal
@@ -454,9 +454,9 @@ class Engine:
             for part in range(n_parts):
                 _lib.check(self.L.mdd_substr_mark(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
                                                   _ptr(table), table.numel(), _ptr(dup)), "mdd_substr_mark")
+            del table
         self.last_substr_parts = n_parts
         self.last_substr_method = method
-        del table
         _lib.check(self.L.mdd_substr_check(self.ctx, None), "mdd_substr_mark")      # an undersized table is an error, not a miss
         kept_b = torch.zeros(n, dtype=torch.int64, device=self.device)
         kept_c = torch.zeros(n, dtype=torch.int64, device=self.device)

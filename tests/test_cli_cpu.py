@@ -154,6 +154,31 @@ def test_checkpoint_manifest_roundtrip_and_refusals(tmp_path):
     os.remove(os.path.join(d, "edges.npy"))
     man = C.save(d, p, ids)
     assert "edges" not in man["artifacts"]                      # a listed artifact whose file is gone is dropped
+    # a NEW run in a reused directory must never list stale edges / labels next to fresh signatures ...
+    C.save(d, p, ids, edges=np.array([[1, 0]], np.uint32), labels=np.array([0, 0, 2], np.uint32))
+    man = C.save(d, p, ids, signatures=sig + 1)
+    assert sorted(man["artifacts"]) == ["doc_ids", "signatures"]
+    with pytest.raises(C.CheckpointError, match="no 'labels'"):
+        C.load(d, "labels", p)
+    # ... other documents (same count) carry nothing over either ...
+    C.save(d, p, ids, edges=np.array([[1, 0]], np.uint32))
+    man = C.save(d, p, ["a", "b", "x"], labels=np.array([0, 1, 2], np.uint32))
+    assert sorted(man["artifacts"]) == ["doc_ids", "labels"]
+    # ... what was read (field, normalisation) is part of the parameters, and the input directory is checked
+    class A:
+        width, ngram_unit, num_perm, bands, rows, seed, content_field_name = 13, "char", 4, 2, 2, 1, "raw_content"
+    pa = C.params_of(A)
+    assert pa["normalize"] == "en" and pa["content_field"] == "raw_content" and pa["id_field"] == "doc_id"
+    C.save(d, pa, ids, signatures=sig, extra={"input_dir": "/data/in"})
+    assert C.load(d, "signatures", pa, "/data/in")["doc_ids"] == ids
+    with pytest.raises(C.CheckpointError, match="written for input"):
+        C.load(d, "signatures", pa, "/data/other")
+    with pytest.raises(C.CheckpointError, match="other parameters"):
+        C.load(d, "signatures", dict(pa, content_field="text"))
+    with open(os.path.join(d, "doc_ids.json"), "w") as f:
+        json.dump(["a", "b", "tampered"], f)
+    with pytest.raises(C.CheckpointError, match="digest"):
+        C.load(d, "signatures", pa)
 
 
 def test_stage_cli_checkpoint_and_resume(tmp_path, mini_docs):
@@ -188,3 +213,61 @@ def test_stage_cli_checkpoint_and_resume(tmp_path, mini_docs):
     fresh = stage.run(stage.build_parser().parse_args(["--input_dir", str(inp), "--normalize", "none", "--workers", "1", "--bands", "14", "--rows", "9",
                                                        "--output_dir", str(tmp_path / "o_fresh")]), engine_factory=lambda d: OracleBackend())
     assert swept["removed_ids.txt"] == open(tmp_path / "o_fresh" / "removed_ids.txt").read() and fresh["n_removed_ids"] > 0
+
+
+def test_artifact_unpickler_refuses_code(tmp_path):
+    """cli/zh_common.read_own_pickle loads plain containers only: a pickle that names any other
+    global -- the way a pickle executes code -- is refused; the real artifact shapes load unchanged."""
+    import pickle
+
+    from map_neo_amd.cli import zh_common as Z
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    p = tmp_path / "evil.pkl"
+    p.write_bytes(pickle.dumps(Evil()))
+    with pytest.raises(pickle.UnpicklingError):
+        Z.read_own_pickle(str(p))
+    assert not (tmp_path / "pwned").exists()
+    arts = [[{"doc_id": "f.jsonl@3", "hash": b"\x00" * 104}], ([[0, 5], [1]], 2, {0: "f@0", 1: "f@1", 5: "g@2"}), {3, 4, 9}, set()]
+    for proto in (2, 3, 4, 5):
+        for a in arts:
+            p.write_bytes(pickle.dumps(a, protocol=proto))
+            assert Z.read_own_pickle(str(p)) == a
+
+
+def test_text_mode_newlines_like_the_reference(tmp_path):
+    """ZH-1:40-42 / ZH-5:9-13 open their files in text mode: "\\r\\n" and a lone "\\r" end a line, and ZH-5 writes every kept
+    line back with "\\n".  Line numbering (ingest) and the filtered copy (egress) follow that on a mixed fixture."""
+    from map_neo_amd import hostio
+    from map_neo_amd.cli import zh_common as Z
+    rows = ['{"text": "row %d %s"}' % (k, "x" * (k % 7)) for k in range(12)]
+    ends = ["\n", "\r\n", "\r", "\r\n", "\n", "\r", "\r", "\n", "\r\n", "\n", "\r", ""]
+    src = tmp_path / "mixed.jsonl"
+    src.write_bytes("".join(r + e for r, e in zip(rows, ends)).encode())
+    # the reference's enumeration
+    with open(src, "r") as f:
+        ref_lines = list(f)
+    assert len(ref_lines) == 12 and all(ln.endswith("\n") for ln in ref_lines[:-1])
+    line_no, text, offs = Z.read_jsonl_texts(str(src), "text")
+    assert line_no.tolist() == list(range(12))
+    got = [bytes(text[int(offs[k]):int(offs[k + 1])]).decode() for k in range(12)]
+    assert got == [json.loads(r)["text"] for r in rows]
+    # "\r\n"-only files keep the native reader and the same numbering
+    crlf = tmp_path / "crlf.jsonl"
+    crlf.write_bytes("\r\n".join(rows).encode())
+    assert Z.read_jsonl_texts(str(crlf), "text")[0].tolist() == list(range(12))
+    for path in (src, crlf):
+        drop = {1, 2, 6, 11}
+        with open(path, "r") as f, open(tmp_path / "ref.out", "w") as fw:       # ZH-5:9-13 restated
+            for idx, line in enumerate(f):
+                if idx not in drop:
+                    fw.write(line)
+        Z.copy_without_lines(str(path), str(tmp_path / "got.out"), drop)
+        assert (tmp_path / "got.out").read_bytes() == (tmp_path / "ref.out").read_bytes()
+        Z.copy_without_lines(str(path), str(tmp_path / "got2.out"), set())
+        with open(path, "r") as f:
+            assert (tmp_path / "got2.out").read_bytes() == f.read().encode()

@@ -202,3 +202,29 @@ def test_word_unit_on_runs_of_spaces_both_oracles():
         a = RC.signatures(buf, offs, 64, w, "word")
         b = np.stack([R.signature(d, 64, w, "word") for d in docs])
         assert (a == b).all(), w
+
+
+def test_word_unit_golden_vector_built_independently():
+    """one vector for the word unit whose expectation does not come from either restatement -- the five word
+    5-grams of the pangram typed out literally (nltk.ngrams over text.split(' '), joined with ' '), their SHA-1 digests
+    as published by `sha1sum`, and datasketch's sha1_hash32 = little-endian u32 of digest[0:4].  Only valid on
+    single-space-normalised text: that is where the word unit is defined (include/mdd.h, MDD_UNIT_WORD)."""
+    text = "the quick brown fox jumps over the lazy dog"
+    grams = [b"the quick brown fox jumps", b"quick brown fox jumps over", b"brown fox jumps over the", b"fox jumps over the lazy",
+             b"jumps over the lazy dog"]
+    digests = ["51fa0448c76be2aa3a49f6075538840570b2a775", "4f820428fcb18cbf72445e9b09edf5140a7a60ae",
+               "28f7fce3b192225884f4f32f06ed1e0b784b4fce", "3df76e625831339639c6a60f83f4af4195b8a50e",
+               "c767d6926710d7bd08432685bba6a2a675a0dfec"]
+    hv = [1208285777, 671384143, 3825006376, 1651439421, 2463524807]
+    assert [" ".join(text.split(" ")[i:i + 5]).encode() for i in range(5)] == grams
+    assert R.shingles_word(text, 5) == grams
+    import hashlib
+    assert [hashlib.sha1(g).hexdigest() for g in grams] == digests
+    assert [int.from_bytes(bytes.fromhex(d)[:4], "little") for d in digests] == hv
+    assert [R.sha1_hash32(g) for g in grams] == hv
+    a, b = R.make_perms(1, 128)
+    exp = R.permute_min(np.array(hv, dtype=np.uint64), a, b)
+    from map_neo_amd.minhash import pack_texts
+    buf, offs = pack_texts([text])
+    assert (RC.signatures(buf, offs, 128, 5, "word")[0] == exp.astype(np.uint32)).all()
+    assert (R.signature(text, 128, 5, "word") == exp.astype(np.uint32)).all()
