@@ -191,17 +191,23 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
     out["exact_substr_dedup"] = {"ms": ms, "docs": k, "docs_per_s": k / ms * 1e3, "text_gb_per_s": sb / ms / 1e6,
                                  "windows_per_s": n_win / ms * 1e3, "bytes_out": int(so2[-1].item()), "docs_out": int(sd.numel()),
                                  "method": eng.last_substr_method, "passes": eng.last_substr_parts}
+    # ALGORITHMIC bytes of the stage = what it must read and write whatever the method: the text in, one mark per byte
+    # position written and read back, the surviving text out (the sort's own traffic is not algorithmic)
+    alg = sb + 2 * sb + int(so2[-1].item())
+    out["exact_substr_dedup"].update({"algorithmic_bytes": alg, "hbm_frac": alg / ms / 1e6 / HBM})
     if eng.last_substr_method == "sorted":
-        # per window: entry written + d1 (10 B), read and rewritten by two scatter levels (2 x 16 B + 2 B), read by the count
-        # pass and by the leaves (16 B), ~15 % of the windows verified on two 64-byte lines; text read by emit and by the
-        # two compaction passes, dup marks written and read, survivors written
-        alg = n_win * (10 + 34 + 16) + int(0.15 * n_win) * 256 + 3 * sb + 3 * sb + int(so2[-1].item())
+        # implementation bytes, per window: entry written + d1 (10 B), read and rewritten by two scatter levels (2 x 16 B + 2 B),
+        # read by the count pass and by the leaves (16 B), ~15 % of the windows verified on two 64-byte lines; text read by
+        # emit and by the two compaction passes, dup marks written and read, survivors written
+        impl = n_win * (10 + 34 + 16) + int(0.15 * n_win) * 256 + 3 * sb + 3 * sb + int(so2[-1].item())
         out["exact_substr_dedup"].update({
-            "algorithmic_bytes": alg, "hbm_frac": alg / ms / 1e6 / HBM,
+            "implementation_bytes_model": impl, "implementation_hbm_frac": impl / ms / 1e6 / HBM,
             "note": "windows sorted into 2^22 leaves (two LDS-sorted scatter levels) and grouped in LDS, bytes compared on tag "
-                    "matches; bounded by random DRAM accesses (~17.5 G/s): level-1 runs of 6 entries and two text lines per "
-                    "verified window; kernels: emit 15.3, scatter 16.8 + 8.7, count 3.5, leaves 30.5, compaction 12 ms "
-                    "(profiles/r2c_substr_kernels.txt); the table method (one random atomic per window) takes 174 ms"})
+                    "matches.  hbm_frac prices the stage against what it must move (text in, marks, text out); the sort's own "
+                    "traffic is implementation_bytes_model (PMC, profiles/r2h_pmc_bench/summary.json: 271 GB per pass with "
+                    "FETCH_SIZE doubled as calibrated on streaming kernels -- for leaf_kernel's scattered 64-byte requests the "
+                    "doubling is not validated, its 110.7 GB may be ~55).  Bounded by random DRAM accesses (~17.5 G/s of runs / "
+                    "~41 G scattered 64-byte requests/s): level-1 runs of 6 entries and two text lines per verified window"})
     else:
         out["exact_substr_dedup"].update({
             "random_atomics": n_win, "atomic_floor_ms": n_win / 17.5e9 * 1e3,
