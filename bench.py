@@ -204,9 +204,9 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
             "implementation_bytes_model": impl, "implementation_hbm_frac": impl / ms / 1e6 / HBM,
             "note": "windows sorted into 2^22 leaves (two LDS-sorted scatter levels) and grouped in LDS, bytes compared on tag "
                     "matches.  hbm_frac prices the stage against what it must move (text in, marks, text out); the sort's own "
-                    "traffic is implementation_bytes_model (PMC, profiles/r2h_pmc_bench/summary.json: 271 GB per pass with "
-                    "FETCH_SIZE doubled as calibrated on streaming kernels -- for leaf_kernel's scattered 64-byte requests the "
-                    "doubling is not validated, its 110.7 GB may be ~55).  Bounded by random DRAM accesses (~17.5 G/s of runs / "
+                    "traffic is implementation_bytes_model (PMC, profiles/r3_pmc_bench/summary.json: ~216 GB per pass -- "
+                    "FETCH_SIZE doubled for the streaming kernels, at face value for leaf_kernel, whose reads are scattered 64-byte "
+                    "requests: the calibration kernels count 63.9 B per scattered 16-byte load).  Bounded by random DRAM accesses (~17.5 G/s of runs / "
                     "~41 G scattered 64-byte requests/s): level-1 runs of 6 entries and two text lines per verified window"})
     else:
         out["exact_substr_dedup"].update({
@@ -438,7 +438,7 @@ def main():
         # profiles/<round>_pmc_bench/summary.json, FETCH_SIZE corrected x2 as calibrated); never measured inside this
         # run (counters need rocprofv3), so the line names the file it comes from, or null if the workload differs
         traffic, traffic_source = None, None
-        for cand in ("r2h_pmc_bench", "r2_pmc_bench", "r1m_pmc_bench"):
+        for cand in ("r3_pmc_bench", "r2h_pmc_bench", "history/r2_pmc_bench", "history/r1m_pmc_bench"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", cand, "summary.json")))
                 if pm["workload"]["text_bytes_per_gpu"] == text_bytes and pm["workload"]["docs_per_gpu"] == n_local:
