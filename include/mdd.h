@@ -370,6 +370,39 @@ int mdd_normalize_en_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
 int mdd_gather_docs(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                     const uint64_t* sel, uint64_t n_sel, const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity);
 
+/* Device-side field extraction for UNCOMPRESSED JSON-lines shards (the ingest on the input side of
+ * the path; csrc/mdd_jsonl.hip).  Replaces, for the lines it can vouch for, the reference's per-line host work --
+ * ZH-1:40-46 `for idx, line in enumerate(f): json.loads(line)[field]`, EN:120-123 spark.read.json + row[field], row["doc_id"]
+ * -- under the contract of the host scanner (include/mdd_io.h): a line is extracted exactly as json.loads would, or handed
+ * back untouched (MDD_JSONL_FALLBACK) for the reference's own Python steps.  `raw` = the shard's bytes in HBM, 16-byte
+ * aligned, with MDD_TEXT_PAD spare bytes after raw_bytes.
+ *   count_lines  tile_counts[t] = "\n" bytes of 16 KiB tile t (u32[ceil(raw_bytes / MDD_JSONL_TILE)]); totals (device
+ *                u64[2], cleared by the call): [0] = "\n" bytes, [1] = lone "\r" bytes (a text-mode reader ends a line there:
+ *                send such a shard to the host reader).  n_lines = totals[0] + (last byte is not "\n").
+ *   line_begins  line_begin[0 .. n_lines] (u64; line i = [line_begin[i], line_begin[i+1]), its "\n" included); tile_base =
+ *                the caller's exclusive prefix sum of tile_counts (u64 per tile).
+ *   scan         per line: status (MDD_JSONL_*), content_pos = position of the opening quote of the content string,
+ *                content_len = its decoded utf-8 length (both 0 unless status is OK), and -- when id_key is not NULL --
+ *                id_kind (MDD_IO_ID_* of include/mdd_io.h: 0 absent / null, 1 plain string, 2 JSON token) with the byte
+ *                range [id_beg, id_end) of the id inside raw.  Keys: HOST strings of 1..64 bytes that need no JSON
+ *                escaping (otherwise MDD_ERR_UNSUPPORTED: use the host reader).  The last duplicate key wins.
+ *   decode       the decoded content of every OK line at out_text[out_offsets[i] ..) (out_offsets = the caller's
+ *                exclusive prefix sum of content_len; nothing is written at or beyond out_capacity): escapes,
+ *                \uXXXX and surrogate pairs resolved -- the packed utf-8 mdd_signatures consumes. */
+#define MDD_JSONL_TILE 16384
+#define MDD_JSONL_OK 0        /* content extracted */
+#define MDD_JSONL_NOCONTENT 1 /* valid JSON object without a usable string in the content field: never hashed, always kept */
+#define MDD_JSONL_FALLBACK 2  /* not vouched for: the caller runs json.loads on the line */
+#define MDD_JSONL_BLANK 3     /* only whitespace: no row */
+int mdd_jsonl_count_lines(mdd_ctx* ctx, const uint8_t* raw, uint64_t raw_bytes, uint32_t* tile_counts, uint64_t* totals);
+int mdd_jsonl_line_begins(mdd_ctx* ctx, const uint8_t* raw, uint64_t raw_bytes, const uint64_t* tile_base, uint64_t* line_begin,
+                          uint64_t n_lines);
+int mdd_jsonl_scan(mdd_ctx* ctx, const uint8_t* raw, uint64_t raw_bytes, const uint64_t* line_begin, uint64_t n_lines,
+                   const char* content_key, const char* id_key, uint8_t* status, uint64_t* content_pos, uint64_t* content_len,
+                   uint8_t* id_kind, uint64_t* id_beg, uint64_t* id_end);
+int mdd_jsonl_decode(mdd_ctx* ctx, const uint8_t* raw, uint64_t raw_bytes, uint64_t n_lines, const uint8_t* status,
+                     const uint64_t* content_pos, const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity);
+
 /* Measurement helper: runs `iters` iterations of a dependency-free
  * v_xor/v_add/v_lshr mix on every CU and reports the measured int32 VALU lane-op rate in
  * *tops_host (HOST double, 1e12 lane-ops/s).  Synchronous. */

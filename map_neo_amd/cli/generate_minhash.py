@@ -27,6 +27,9 @@ def build_parser():
     p.add_argument("--rows", type=int, default=Z.ROWS)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--ingest", choices=["device", "host"], default="device",
+                   help="who extracts the content field (ZH-1:40-46): the GPU from the shard's raw bytes (default; unsure lines, "
+                        "gzip shards go through the host reader) or host threads")
     return p
 
 
@@ -39,14 +42,36 @@ def process_dir(args):
         os.makedirs(os.path.join(args.output_dir, str(band)), exist_ok=True)
     files = hostio.list_files(args.input_dir)
     # shards are parsed on threads ahead of the device; --workers (the reference's pool size, default 42) is capped
-    for fi, line_no, text, offs in Z.iter_shards(files, args.content_field_name, min(16, args.workers)):   # no normalisation in the ZH path (ZH-1:46)
+    def per_file():
+        """(file index, line numbers, signatures u32 [n, K]) for every file with documents"""
+        if args.ingest == "device":
+            for fidx, line_no, text, offs, nbytes in Z.iter_shards_device(eng, files, args.content_field_name, min(16, args.workers)):
+                sig = as_u32(eng.signatures(text, offs, args.num_perm, args.width, args.ngram_unit, args.seed, text_bytes=nbytes))
+                sig = sig.reshape(len(line_no), args.num_perm)
+                for fi in np.unique(fidx).tolist():           # a batch holds several files: split its rows
+                    m = fidx == fi
+                    yield fi, line_no[m], sig[m]
+        else:
+            for fi, line_no, text, offs in Z.iter_shards(files, args.content_field_name, min(16, args.workers)):
+                buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+                buf[: text.size] = text
+                sig = as_u32(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width, args.ngram_unit,
+                                            args.seed, text_bytes=int(text.size)))
+                yield fi, line_no, sig.reshape(len(line_no), args.num_perm)
+
+    seen = set()
+
+    def with_empty_files():      # ZH-1:58-61 writes its (empty) band lists for a file without documents too
+        for item in per_file():
+            seen.add(item[0])
+            yield item
+        for fi in range(len(files)):
+            if fi not in seen:
+                yield fi, np.zeros(0, np.uint64), np.zeros((0, args.num_perm), np.uint32)
+
+    for fi, line_no, sig in with_empty_files():   # no normalisation in the ZH path (ZH-1:46)
         name = os.path.basename(files[fi])
         print(f"process file {name}")
-        buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-        buf[: text.size] = text
-        sig = as_u32(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
-                                    args.ngram_unit, args.seed, text_bytes=int(text.size)))
-        sig = sig.reshape(len(line_no), args.num_perm)
         ids = [f"{name}@{idx}" for idx in line_no.tolist()]
         for band in range(args.bands):
             keys = Z.band_key_bytes(sig, band, args.rows)

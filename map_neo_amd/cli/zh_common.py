@@ -51,6 +51,54 @@ def iter_shards(files, field: str, workers: int):
             yield (fi,) + tuple(res)
 
 
+def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 256 << 20):
+    """iter_shards with the field extraction on the device (hostio.read_jsonl_batch_device): the files are taken in
+    batches of about `batch_bytes`; threads only read a batch's files into ONE pinned host buffer (the next batch while
+    the GPU works on this one), the GPU finds the lines, validates and decodes them.  Yields per batch
+    (file indices int64 per document, line numbers uint64 per document, text DEVICE uint8 padded, offsets DEVICE int64
+    [n+1], text_bytes).  gzip shards, batches with a lone "\\r" and unsuitable field names go through the host reader."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ..minhash import padded_size
+    workers = max(1, int(workers or 1))
+    batches, cur, size = [], [], 0
+    for k, p in enumerate(files):
+        sz = os.path.getsize(p)
+        if cur and size + sz > batch_bytes:
+            batches.append(cur)
+            cur, size = [], 0
+        cur.append(k)
+        size += sz
+    if cur:
+        batches.append(cur)
+
+    def host_route(k):
+        line_no, text, offs = read_jsonl_texts(files[k], field)
+        buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+        buf[: text.size] = text
+        return (np.full(len(line_no), k, dtype=np.int64), line_no, eng.to_device(buf), eng.to_device(np.ascontiguousarray(offs)),
+                int(text.size))
+
+    with ThreadPoolExecutor(workers) as rpool, ThreadPoolExecutor(1) as bpool:
+        read = lambda b: hostio.read_files_pinned([files[k] for k in b], rpool)      # noqa: E731
+        nxt = bpool.submit(read, batches[0]) if batches else None
+        for bi, b in enumerate(batches):
+            pre = nxt.result()
+            nxt = bpool.submit(read, batches[bi + 1]) if bi + 1 < len(batches) else None
+            r = hostio.read_jsonl_batch_device(eng, [files[k] for k in b], field, None, on_error="skip", pre=pre)
+            del pre
+            if r is None:
+                for k in b:
+                    yield host_route(k)
+                continue
+            for j in np.flatnonzero(r["n_bad"]).tolist():
+                print(f"procces file {os.path.basename(files[b[j]])}: {int(r['n_bad'][j])} lines skipped (not JSON objects)")
+            cand = r["cand"]
+            yield np.asarray(b, dtype=np.int64)[r["file_of"][cand]], r["line_no"][cand], r["text"], r["offsets"], r["text_bytes"]
+            for j in r["host_files"]:
+                yield host_route(b[j])
+
+
 def band_key_bytes(sig_u32: np.ndarray, band: int, rows: int) -> List[bytes]:
     """_H (ZH-1:20-21): 8-byte big-endian serialisation of hashvalues[band*r:(band+1)*r]."""
     blk = np.ascontiguousarray(sig_u32[:, band * rows:(band + 1) * rows]).astype(">u8")

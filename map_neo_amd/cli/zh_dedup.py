@@ -30,7 +30,14 @@ def build_parser():
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1), help="threads that parse / rewrite shards")
+    p.add_argument("--ingest", choices=["device", "host"], default="device",
+                   help="who extracts the content field (ZH-1:40-46).  device: the shard's bytes go to HBM and the GPU finds the "
+                        "lines, validates and decodes them (lines it cannot vouch for, gzip shards and shards with a lone \\r go "
+                        "through the host reader); host: libmdd_io.so / json.loads on --workers threads")
     return p
+
+
+last_stats = {}      # phase times of the most recent run() (tools/e2e_cli.py reads them)
 
 
 class _Ids:
@@ -54,29 +61,49 @@ def run(args):
     import torch
     from concurrent.futures import ThreadPoolExecutor
     names = [os.path.basename(p) for p in files]
+    import time
+    t0 = time.time()
     # Shards are parsed on threads (the native reader holds no GIL) and consumed in file order, so parsing runs ahead
     # of the device; one shard's text is in HBM at a time, the signatures of all of them stay there.
     file_of, line_of, sigs = [], [], []
     eng = None
-    for fi, line_no, text, offs in Z.iter_shards(files, args.content_field_name, args.workers):
-        if eng is None:
-            eng = Engine(args.device)                    # comes up while the next shards are being parsed
-        if not len(line_no):
-            continue
-        file_of.append(np.full(len(line_no), fi, dtype=np.int64))
-        line_of.append(line_no.astype(np.int64))
-        buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-        buf[: text.size] = text
-        sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
-                                   args.ngram_unit, args.seed, text_bytes=int(text.size)))
+    if args.ingest == "device":
+        eng = Engine(args.device)
+        for fidx, line_no, text, offs, nbytes in Z.iter_shards_device(eng, files, args.content_field_name, args.workers):
+            if not len(line_no):
+                continue
+            file_of.append(fidx)
+            line_of.append(line_no.astype(np.int64))
+            sigs.append(eng.signatures(text, offs, args.num_perm, args.width, args.ngram_unit, args.seed, text_bytes=nbytes))
+        if file_of:      # batches come in file order except for gzip shards of a batch (host route): restore (file, line) order
+            fo, lo = np.concatenate(file_of), np.concatenate(line_of)
+            order = np.lexsort((lo, fo))
+            if not (order == np.arange(len(order))).all():
+                sig_all = torch.cat(sigs)[eng.to_device(order.astype(np.int64))]
+                file_of, line_of, sigs = [fo[order]], [lo[order]], [sig_all]
+    else:
+        for fi, line_no, text, offs in Z.iter_shards(files, args.content_field_name, args.workers):
+            if eng is None:
+                eng = Engine(args.device)                    # comes up while the next shards are being parsed
+            if not len(line_no):
+                continue
+            file_of.append(np.full(len(line_no), fi, dtype=np.int64))
+            line_of.append(line_no.astype(np.int64))
+            buf = np.zeros(padded_size(text.size), dtype=np.uint8)
+            buf[: text.size] = text
+            sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                                       args.ngram_unit, args.seed, text_bytes=int(text.size)))
     if eng is None:
         eng = Engine(args.device)
     file_of = np.concatenate(file_of) if file_of else np.zeros(0, np.int64)
     line_of = np.concatenate(line_of) if line_of else np.zeros(0, np.int64)
     ids = _Ids(names, file_of, line_of)
     sig = torch.cat(sigs) if sigs else torch.empty((0, args.num_perm), dtype=torch.int32, device=eng.device)
+    torch.cuda.synchronize(eng.device)
+    t1 = time.time()
     out = cluster_local(eng, sig, args.bands, args.rows)
     labels = as_u32(out["labels"])
+    t2 = time.time()
     removed = labels != np.arange(len(ids), dtype=np.uint32)
     drop = [set() for _ in files]                        # per input file: line numbers to leave out (ZH-4:15-22)
     rk = np.flatnonzero(removed)
@@ -89,6 +116,9 @@ def run(args):
 
     with ThreadPoolExecutor(max(1, args.workers)) as pool:
         list(pool.map(copy_kept, range(len(files))))
+    global last_stats
+    last_stats = {"ingest": args.ingest, "t_read_extract_signatures_s": t1 - t0, "t_cluster_s": t2 - t1, "t_write_s": time.time() - t2,
+                  "input_bytes": int(sum(os.path.getsize(p) for p in files)), "n_docs": len(ids)}
     n_comp = int((labels == np.arange(len(ids))).sum())
     print("number of connected components:", n_comp)
     print("number of duplicate documents that will be removed:", int(removed.sum()))

@@ -340,6 +340,151 @@ def read_jsonl_shard(path: str, content_field: str, id_field=None, normalize_en:
             "text": np.frombuffer(b"".join(enc), dtype=np.uint8), "offsets": offs2, "n_bad": n_bad}
 
 
+def read_files_pinned(paths, pool=None):
+    """The bytes of several plain (not gzip) files back to back in ONE pinned host tensor (torch's caching host allocator:
+    the buffer is reused once freed), every file followed by a "\\n" (so a last line without one is closed; after a file that
+    ends with "\\n" it is a blank line, which is no row).  Returns (uint8 tensor, starts int64 [n+1], is_gzip bool [n]): file
+    k occupies [starts[k], starts[k+1]) including its added "\\n"; a gzip file's range is blanked (it goes to the host reader).
+    `pool` (a ThreadPoolExecutor) reads the files side by side; the reads release the GIL."""
+    import numpy as np
+    import torch
+    sizes = [os.path.getsize(p) for p in paths]
+    starts = np.zeros(len(paths) + 1, dtype=np.int64)
+    starts[1:] = np.cumsum([sz + 1 for sz in sizes])
+    buf = torch.empty(max(int(starts[-1]), 1), dtype=torch.uint8, pin_memory=True)
+    mv = memoryview(buf.numpy())
+    is_gz = np.zeros(len(paths), dtype=bool)
+
+    def one(k):
+        lo, n = int(starts[k]), sizes[k]
+        got = 0
+        with open(paths[k], "rb") as f:
+            while got < n:
+                r = f.readinto(mv[lo + got: lo + n])
+                if not r:
+                    break
+                got += r
+        if got >= 2 and mv[lo] == 0x1f and mv[lo + 1] == 0x8b:
+            is_gz[k] = True
+            got = 0
+        if got < n:                                   # gzip, or a file that shrank meanwhile: blank out the rest
+            buf[lo + got: lo + n] = 32
+        mv[lo + n] = 10
+    if pool is not None and len(paths) > 1:
+        list(pool.map(one, range(len(paths))))
+    else:
+        for k in range(len(paths)):
+            one(k)
+    return buf, starts, is_gz
+
+
+def read_jsonl_batch_device(eng, paths, content_field: str, id_field=None, on_error: str = "skip", pre=None):
+    """read_jsonl_shard for SEVERAL uncompressed shards at once with the field extraction ON THE DEVICE
+    (Engine.jsonl_extract, csrc/mdd_jsonl.hip): the shards' bytes go files -> one pinned host buffer -> HBM, the GPU finds
+    the lines, validates every line it vouches for and decodes the content field into packed utf-8 that never leaves HBM;
+    lines it hands back (status fallback) run through `_py_line` (json.loads) here, exactly as in the host reader, and are
+    merged in line order.  One call per batch instead of one per shard: the per-call latencies (a handful of host
+    synchronisations, a scan kernel whose run time is the longest line's) are paid once.  Returns a dict
+      file_of   int64 per ROW: index into `paths`;   line_no  uint64 per row: physical line number inside its file
+      ids       list per row (None without id_field);  cand  int64: row index of every document that will be hashed
+      text / offsets / text_bytes   DEVICE tensors: packed utf-8 (padded) and int64 offsets of those documents, in row order
+      n_bad     int64 per file: lines that are not JSON objects
+      host_files  indices of files the device did not take (gzip): read them with read_jsonl_shard
+    or None when nothing can be done on the device for this batch (field names that need JSON escaping, a lone "\\r"
+    somewhere in the batch: text-mode line semantics) -- then every file goes to read_jsonl_shard.
+    `pre` = a read_files_pinned result (prefetched on threads).  No EN normalisation: Engine.signatures_en does that."""
+    import json
+
+    import numpy as np
+    import torch
+
+    from .minhash import pack_texts, padded_size
+    host, starts, is_gz = pre if pre is not None else read_files_pinned(paths)
+    n = int(starts[-1])
+    raw = torch.empty(padded_size(n), dtype=torch.uint8, device=eng.device)
+    raw[:n].copy_(host[:n], non_blocking=True)
+    raw[n:].zero_()
+    x = eng.jsonl_extract(raw, n, content_field, id_field)
+    if x is None or x["lone_cr"]:
+        return None
+    status, lb = x["status"], x["line_begin"].astype(np.int64)
+    first_line = np.searchsorted(lb[:-1], starts[:-1], side="left")      # global index of every file's line 0
+    rows = np.flatnonzero(status != 3)                                    # physical lines that are rows (blank lines are none)
+    fb = np.flatnonzero(status == 2)
+    hb = host.numpy()
+    ids_of = {}
+    if id_field:
+        idk, idb, ide = x["id_kind"], x["id_beg"], x["id_end"]
+        for i in np.flatnonzero(idk == 1).tolist():
+            ids_of[i] = hb[int(idb[i]):int(ide[i])].tobytes().decode("utf8")
+        for i in np.flatnonzero(idk == 2).tolist():
+            ids_of[i] = json.loads(hb[int(idb[i]):int(ide[i])].tobytes())
+    fb_docs, bad = {}, []
+    for i in fb.tolist():                                                 # lines handed back: the reference's own steps
+        try:
+            line = hb[int(lb[i]):int(lb[i + 1])].tobytes().decode("utf8")
+            ok, rid, data = _py_line(line, content_field, id_field, False, on_error)
+        except UnicodeDecodeError:
+            if on_error == "raise":
+                raise
+            ok, rid, data = False, None, None
+        if not ok:
+            bad.append(i)
+            continue
+        ids_of[i] = rid
+        if data is not None:
+            fb_docs[i] = data
+    bad = np.asarray(bad, dtype=np.int64)
+    if len(bad):
+        rows = rows[~np.isin(rows, bad)]
+    file_of_line = lambda lines: np.searchsorted(first_line, lines, side="right") - 1      # noqa: E731
+    n_bad = np.bincount(file_of_line(bad), minlength=len(paths)) if len(bad) else np.zeros(len(paths), dtype=np.int64)
+    ids = [ids_of.get(i) for i in rows.tolist()] if id_field else [None] * len(rows)
+    row_of_line = np.full(x["n_lines"] + 1, -1, dtype=np.int64)
+    row_of_line[rows] = np.arange(len(rows))
+    ok_lines = x["ok_lines"]
+    text, offsets, total = x["text"], x["offsets"], x["text_bytes"]
+    if fb_docs:
+        # merge the handed-back documents in line order: [device docs | fallback docs] gathered by line
+        fl = np.fromiter(sorted(fb_docs), dtype=np.int64)
+        buf, fo = pack_texts([fb_docs[i] for i in fl.tolist()])
+        ft, fo = eng.to_device(buf), eng.to_device(fo)
+        cat_text = torch.cat([text[:total], ft])
+        cat_offs = torch.cat([offsets, fo[1:] + total])
+        all_lines = np.concatenate([ok_lines, fl])
+        order = np.argsort(all_lines, kind="stable")
+        text, offsets = eng.gather_docs(cat_text, cat_offs, eng.to_device(order.astype(np.int64)))
+        total = int(offsets[-1].item())
+        cand_lines = all_lines[order]
+    else:
+        cand_lines = ok_lines
+    fo_rows = file_of_line(rows)
+    return {"file_of": fo_rows, "line_no": (rows - first_line[fo_rows]).astype(np.uint64), "ids": ids,
+            "cand": row_of_line[cand_lines], "text": text, "offsets": offsets, "text_bytes": total, "n_bad": n_bad,
+            "host_files": np.flatnonzero(is_gz).tolist(), "device_lines": int(len(ok_lines)), "fallback_lines": int(len(fb))}
+
+
+def read_jsonl_shard_device(eng, path: str, content_field: str, id_field=None, on_error: str = "skip"):
+    """read_jsonl_shard with the field extraction on the device (a batch of one: read_jsonl_batch_device).  Same result
+    keys as read_jsonl_shard, except that `text` (uint8, padded) and `offsets` (int64) are DEVICE tensors and `text_bytes`
+    is added.  gzip shards, shards holding a lone "\\r" (text-mode line semantics) and field names that need JSON escaping
+    are read by read_jsonl_shard and uploaded."""
+    import numpy as np
+
+    from .minhash import padded_size
+    r = read_jsonl_batch_device(eng, [path], content_field, id_field, on_error)
+    if r is None or r["host_files"]:
+        h = read_jsonl_shard(path, content_field, id_field, False, on_error)
+        t = np.zeros(padded_size(h["text"].size), dtype=np.uint8)
+        t[: h["text"].size] = h["text"]
+        return {"ids": h["ids"], "line_no": h["line_no"], "cand": h["cand"], "text": eng.to_device(t),
+                "offsets": eng.to_device(np.ascontiguousarray(h["offsets"])), "text_bytes": int(h["text"].size), "n_bad": h["n_bad"],
+                "device_lines": 0, "fallback_lines": 0}
+    return {"ids": r["ids"], "line_no": r["line_no"], "cand": r["cand"], "text": r["text"], "offsets": r["offsets"],
+            "text_bytes": r["text_bytes"], "n_bad": int(r["n_bad"][0]), "device_lines": r["device_lines"],
+            "fallback_lines": r["fallback_lines"]}
+
+
 # ------------------------------------------------------------------------------------------
 # Parquet ingest without per-row Python objects: Arrow string buffers are already the packed
 # utf-8 + offsets layout mdd_signatures consumes

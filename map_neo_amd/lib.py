@@ -58,6 +58,10 @@ SIGNATURES = {
     "mdd_normalize_en_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _u64]),
     "mdd_gather_docs": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64]),
     "mdd_exact_group": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _vp, _vp]),
+    "mdd_jsonl_count_lines": (_int, [_vp, _vp, _u64, _vp, _vp]),
+    "mdd_jsonl_line_begins": (_int, [_vp, _vp, _u64, _vp, _vp, _u64]),
+    "mdd_jsonl_scan": (_int, [_vp, _vp, _u64, _vp, _u64, C.c_char_p, C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mdd_jsonl_decode": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _u64]),
     "mdd_valu_calibrate": (_int, [_vp, _int, C.POINTER(C.c_double)]),
 }
 

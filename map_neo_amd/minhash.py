@@ -536,6 +536,59 @@ class Engine:
                                           _ptr(out_text), total), "mdd_gather_docs")
         return out_text, out_offs
 
+    JSONL_TILE = 16384      # MDD_JSONL_TILE
+
+    def jsonl_extract(self, raw: torch.Tensor, raw_bytes: int, content_field: str, id_field: Optional[str] = None):
+        """Field extraction of an UNCOMPRESSED JSON-lines shard whose bytes are in HBM (mdd_jsonl_*; ZH-1:40-46 / EN:120-123
+        for the lines the device can vouch for).  raw: uint8 device tensor of capacity >= padded_size(raw_bytes).
+        Returns a dict:
+          n_lines, status (uint8 host array per physical line: 0 OK, 1 no content, 2 fallback -- run json.loads on it --, 3 blank),
+          line_begin (uint64 host array [n_lines+1]), lone_cr (lone "\\r" bytes: a text-mode reader splits there),
+          text / offsets (device: packed decoded content of the OK lines, int64 [n_ok+1]), ok_lines (int64 host array),
+          id_kind / id_beg / id_end (host arrays per line; None without id_field).
+        None when the field names need JSON escaping or exceed 64 bytes (MDD_ERR_UNSUPPORTED: use the host reader)."""
+        assert raw.dtype == torch.uint8 and raw.is_cuda and raw.numel() >= int(raw_bytes) + TEXT_PAD
+        raw_bytes = int(raw_bytes)
+        n_tiles = max(1, -(-raw_bytes // self.JSONL_TILE))
+        tile_counts = torch.zeros(n_tiles, dtype=torch.int32, device=self.device)
+        totals = torch.zeros(2, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.mdd_jsonl_count_lines(self.ctx, _ptr(raw), raw_bytes, _ptr(tile_counts), _ptr(totals)), "mdd_jsonl_count_lines")
+        n_nl, lone_cr = (int(x) for x in totals.cpu().tolist())
+        last_open = raw_bytes > 0 and int(raw[raw_bytes - 1].item()) != 10
+        n_lines = n_nl + (1 if last_open else 0)
+        tile_base = torch.cumsum(tile_counts.to(torch.int64), 0) - tile_counts      # exclusive prefix (plumbing)
+        line_begin = torch.zeros(n_lines + 1, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.mdd_jsonl_line_begins(self.ctx, _ptr(raw), raw_bytes, _ptr(tile_base), C.c_void_p(line_begin.data_ptr()), n_lines),
+                   "mdd_jsonl_line_begins")
+        status = torch.empty(n_lines, dtype=torch.uint8, device=self.device)
+        cpos = torch.empty(n_lines, dtype=torch.int64, device=self.device)
+        clen = torch.empty(n_lines, dtype=torch.int64, device=self.device)
+        idk = idb = ide = None
+        if id_field:
+            idk = torch.empty(n_lines, dtype=torch.uint8, device=self.device)
+            idb = torch.empty(n_lines, dtype=torch.int64, device=self.device)
+            ide = torch.empty(n_lines, dtype=torch.int64, device=self.device)
+        rc = self.L.mdd_jsonl_scan(self.ctx, _ptr(raw), raw_bytes, _ptr(line_begin), n_lines, content_field.encode("utf8"),
+                                   id_field.encode("utf8") if id_field else None, _ptr(status), _ptr(cpos), _ptr(clen), _ptr(idk),
+                                   _ptr(idb), _ptr(ide))
+        if rc == -3:                                    # MDD_ERR_UNSUPPORTED: key needs escaping / too long
+            return None
+        _lib.check(rc, "mdd_jsonl_scan")
+        out_offs = torch.zeros(n_lines + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(clen, 0, out=out_offs[1:])
+        total = int(out_offs[-1].item()) if n_lines else 0
+        text = torch.zeros(padded_size(total), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.mdd_jsonl_decode(self.ctx, _ptr(raw), raw_bytes, n_lines, _ptr(status), _ptr(cpos), _ptr(out_offs), _ptr(text),
+                                           total), "mdd_jsonl_decode")
+        ok = torch.nonzero(status == 0).flatten()
+        offsets = torch.cat([out_offs[:-1][ok], out_offs[-1:]])
+        res = {"n_lines": n_lines, "status": status.cpu().numpy(), "line_begin": line_begin.cpu().numpy().view(np.uint64),
+               "lone_cr": lone_cr, "text": text, "offsets": offsets, "text_bytes": total, "ok_lines": ok.cpu().numpy(),
+               "id_kind": None, "id_beg": None, "id_end": None}
+        if id_field:
+            res.update(id_kind=idk.cpu().numpy(), id_beg=idb.cpu().numpy().view(np.uint64), id_end=ide.cpu().numpy().view(np.uint64))
+        return res
+
     def valu_calibrate(self, iters: int = 20000) -> float:
         out = C.c_double(0.0)
         _lib.check(self.L.mdd_valu_calibrate(self.ctx, iters, C.byref(out)), "mdd_valu_calibrate")

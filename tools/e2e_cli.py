@@ -47,15 +47,24 @@ def zh(n, shards, workers):
     timed("generate_dup_line_id_for_each_file", generate_dup_line_id_for_each_file.main, ["--input_file", C, "--output_dir", D])
     timed("remove_dup", remove_dup.main, ["--input_dir", inp, "--output_dir", O, "--dup_line_id_dir", D, "--workers", str(workers)])
     wall5 = time.time() - t_all
-    t0 = time.time()
-    zh_dedup.main(["--input_dir", inp, "--output_dir", O2])
-    wall_fused = time.time() - t0
+    # the fused command with both ingest routes, each twice (the first run of a route pays for page-cache / allocator warm-up)
+    fused = {}
+    in_bytes = sum(os.path.getsize(os.path.join(inp, f)) for f in os.listdir(inp))
     names = sorted(os.listdir(inp))
-    same = all(filecmp.cmp(os.path.join(O, f), os.path.join(O2, f), shallow=False) for f in names)
+    same = True
+    for ingest in ("host", "device", "host", "device"):
+        shutil.rmtree(O2, ignore_errors=True)
+        t0 = time.time()
+        zh_dedup.main(["--input_dir", inp, "--output_dir", O2, "--ingest", ingest, "--workers", str(workers)])
+        w = time.time() - t0
+        fused[ingest] = dict(zh_dedup.last_stats, wall_s=w, docs_per_s=n / w, jsonl_gb_per_s=in_bytes / w / 1e9,
+                             ingest_hash_gb_per_s=in_bytes / zh_dedup.last_stats["t_read_extract_signatures_s"] / 1e9)
+        same = same and all(filecmp.cmp(os.path.join(O, f), os.path.join(O2, f), shallow=False) for f in names)
+    wall_fused = fused["device"]["wall_s"]
     kept = sum(1 for f in names for _ in open(os.path.join(O2, f), "rb"))
-    print(json.dumps({"mode": "zh", "docs": n, "text_bytes": int(o[-1]), "shards": shards, "workers": workers,
+    print(json.dumps({"mode": "zh", "docs": n, "text_bytes": int(o[-1]), "jsonl_bytes": in_bytes, "shards": shards, "workers": workers,
                       "five_commands_wall_s": wall5, "five_commands_docs_per_s": n / wall5, "steps_s": steps,
-                      "fused_wall_s": wall_fused, "fused_docs_per_s": n / wall_fused,
+                      "fused_wall_s": wall_fused, "fused_docs_per_s": n / wall_fused, "fused": fused,
                       "outputs_identical": same, "docs_kept": kept, "docs_removed": n - kept}))
     shutil.rmtree(root, ignore_errors=True)
     assert same, "five-step and fused ZH outputs differ"
