@@ -377,8 +377,9 @@ int mdd_gather_docs(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  * back untouched (MDD_JSONL_FALLBACK) for the reference's own Python steps.  `raw` = the shard's bytes in HBM, 16-byte
  * aligned, with MDD_TEXT_PAD spare bytes after raw_bytes.
  *   count_lines  tile_counts[t] = "\n" bytes of 16 KiB tile t (u32[ceil(raw_bytes / MDD_JSONL_TILE)]); totals (device
- *                u64[2], cleared by the call): [0] = "\n" bytes, [1] = lone "\r" bytes (a text-mode reader ends a line there:
- *                send such a shard to the host reader).  n_lines = totals[0] + (last byte is not "\n").
+ *                u64[3], cleared by the call): [0] = "\n" bytes, [1] = lone "\r" bytes (a text-mode reader ends a line there:
+ *                send such a shard to the host reader), [2] = all "\r" bytes (0: the shard's lines can be copied as byte
+ *                ranges, ZH-5's text-mode rewrite is the identity).  n_lines = totals[0] + (last byte is not "\n").
  *   line_begins  line_begin[0 .. n_lines] (u64; line i = [line_begin[i], line_begin[i+1]), its "\n" included); tile_base =
  *                the caller's exclusive prefix sum of tile_counts (u64 per tile).
  *   scan         per line: status (MDD_JSONL_*), content_pos = position of the opening quote of the content string,

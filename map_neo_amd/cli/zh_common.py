@@ -51,12 +51,14 @@ def iter_shards(files, field: str, workers: int):
             yield (fi,) + tuple(res)
 
 
-def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 256 << 20):
+def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 256 << 20, line_index=None):
     """iter_shards with the field extraction on the device (hostio.read_jsonl_batch_device): the files are taken in
     batches of about `batch_bytes`; threads only read a batch's files into ONE pinned host buffer (the next batch while
     the GPU works on this one), the GPU finds the lines, validates and decodes them.  Yields per batch
     (file indices int64 per document, line numbers uint64 per document, text DEVICE uint8 padded, offsets DEVICE int64
-    [n+1], text_bytes).  gzip shards, batches with a lone "\\r" and unsuitable field names go through the host reader."""
+    [n+1], text_bytes).  gzip shards, batches with a lone "\\r" and unsuitable field names go through the host reader.
+    line_index (a dict, optional) receives {file index: byte offsets of the file's line starts + its size} for the files
+    whose lines can be copied as byte ranges (copy_without_lines)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from ..minhash import padded_size
@@ -93,6 +95,10 @@ def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 
                 continue
             for j in np.flatnonzero(r["n_bad"]).tolist():
                 print(f"procces file {os.path.basename(files[b[j]])}: {int(r['n_bad'][j])} lines skipped (not JSON objects)")
+            if line_index is not None and r["line_starts"] is not None:
+                for j, k in enumerate(b):
+                    if j not in r["host_files"]:
+                        line_index[k] = r["line_starts"][j]
             cand = r["cand"]
             yield np.asarray(b, dtype=np.int64)[r["file_of"][cand]], r["line_no"][cand], r["text"], r["offsets"], r["text_bytes"]
             for j in r["host_files"]:
@@ -114,11 +120,32 @@ def key_bytes_to_tuples(keys: List[bytes], rows: int) -> np.ndarray:
     return arr.astype(np.uint32)
 
 
-def copy_without_lines(src: str, dst: str, drop) -> None:
+def copy_without_lines(src: str, dst: str, drop, line_starts=None) -> None:
     """ZH-5:7-13: copy `src` to `dst` byte for byte without the lines whose index is in `drop`.
     Line i = data[start[i]:start[i+1]] (a last line without "\n" counts, as in `for line in f`); the kept text is
     written as the runs between dropped lines: O(dropped lines) Python steps instead of one per line, so threads
-    copying different files do not queue on the interpreter lock."""
+    copying different files do not queue on the interpreter lock.
+    line_starts (optional; from the device-side line index, only given for plain files without any "\\r"): byte offset of
+    every line start + the file size -- the runs are then copied inside the kernel (os.copy_file_range), the file's bytes
+    never enter this process."""
+    if line_starts is not None and hasattr(os, "copy_file_range"):
+        n_lines = len(line_starts) - 1
+        cuts = sorted(x for x in drop if 0 <= x < n_lines)
+        try:
+            with open(src, "rb") as fi, open(dst, "wb") as fo:
+                pos = 0
+                for d in cuts + [None]:
+                    end = int(line_starts[d]) if d is not None else int(line_starts[-1])
+                    while pos < end:
+                        k = os.copy_file_range(fi.fileno(), fo.fileno(), end - pos, pos)
+                        if k <= 0:
+                            raise OSError("copy_file_range made no progress")
+                        pos += k
+                    if d is not None:
+                        pos = int(line_starts[d + 1])
+            return
+        except OSError:
+            pass                                    # file systems without it (EXDEV, ENOSYS): the byte route below
     with open(src, "rb") as f:
         data = f.read()
     # The reference reads plain text only (ZH-1:40, ZH-5:9); the ingest of these commands also accepts gzip'd shards and

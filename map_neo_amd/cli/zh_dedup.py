@@ -67,9 +67,11 @@ def run(args):
     # of the device; one shard's text is in HBM at a time, the signatures of all of them stay there.
     file_of, line_of, sigs = [], [], []
     eng = None
+    line_index = {}      # device ingest: byte offsets of every file's line starts (for byte-range copies at the end)
     if args.ingest == "device":
         eng = Engine(args.device)
-        for fidx, line_no, text, offs, nbytes in Z.iter_shards_device(eng, files, args.content_field_name, args.workers):
+        for fidx, line_no, text, offs, nbytes in Z.iter_shards_device(eng, files, args.content_field_name, args.workers,
+                                                                      line_index=line_index):
             if not len(line_no):
                 continue
             file_of.append(fidx)
@@ -112,7 +114,7 @@ def run(args):
     os.makedirs(args.output_dir, exist_ok=True)
 
     def copy_kept(k):                                    # ZH-5:7-13; files without duplicates are copied unchanged
-        Z.copy_without_lines(files[k], os.path.join(args.output_dir, names[k]), drop[k])
+        Z.copy_without_lines(files[k], os.path.join(args.output_dir, names[k]), drop[k], line_index.get(k))
 
     with ThreadPoolExecutor(max(1, args.workers)) as pool:
         list(pool.map(copy_kept, range(len(files))))

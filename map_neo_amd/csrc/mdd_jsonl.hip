@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t swar_eq(uint32_t w, uint32_t b) {
     return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
 }
 
-// WRITE = false: tile_counts[tile] = newlines of the tile, totals[0] += them, totals[1] += lone "\r".
+// WRITE = false: tile_counts[tile] = newlines of the tile, totals[0] += them, totals[1] += lone "\r", totals[2] += all "\r".
 // WRITE = true:  line_begin[k + 1] = position after the k-th newline (k counted over the whole shard; tile_base[tile] =
 //                newlines before the tile).
 template <bool WRITE>
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) jsonl_index_kernel(const uint8_t* __restr
     const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(raw);
     const uint64_t seg = (uint64_t)blockIdx.x * TILE_BYTES + (uint64_t)wave * (TILE_BYTES / 4);  // this wave's 4096 bytes
     uint32_t z[16];
-    uint32_t cnt = 0, lone = 0;
+    uint32_t cnt = 0, lone = 0, crs = 0;
 #pragma unroll
     for (int s = 0; s < 16; s++) {
         const uint64_t p = seg + (uint64_t)s * 256 + 4 * lane;
@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) jsonl_index_kernel(const uint8_t* __restr
         if (!WRITE) {
             const uint32_t cr = swar_eq(w, 13u) & in;
             if (cr) {
+                crs += (uint32_t)__builtin_popcount(cr);
                 // followed by "\n"?  bytes 0..2: the next byte of the same dword; byte 3: the next dword's first byte
                 uint32_t follow = (z[s] >> 8);
                 if ((cr >> 31) && p + 4 < n && raw[p + 4] == 10u) follow |= 0x80000000u;
@@ -78,10 +79,14 @@ __global__ void __launch_bounds__(256) jsonl_index_kernel(const uint8_t* __restr
     for (int o = 32; o >= 1; o >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
     if (!WRITE) {
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) lone += (uint32_t)__shfl_xor((int)lone, o, 64);
+        for (int o = 32; o >= 1; o >>= 1) {
+            lone += (uint32_t)__shfl_xor((int)lone, o, 64);
+            crs += (uint32_t)__shfl_xor((int)crs, o, 64);
+        }
         if (lane == 0) {
             wave_cnt[wave] = wsum;
             if (lone) atomicAdd(&totals[1], (unsigned long long)lone);
+            if (crs) atomicAdd(&totals[2], (unsigned long long)crs);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -554,7 +559,7 @@ int mdd_jsonl_count_lines(mdd_ctx* ctx, const uint8_t* raw, uint64_t raw_bytes, 
     REQUIRE(ctx, "mdd_jsonl_count_lines: ctx is NULL");
     REQUIRE(totals, "mdd_jsonl_count_lines: NULL totals");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(uint64_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(totals, 0, 3 * sizeof(uint64_t), ctx->stream));
     if (raw_bytes == 0) return MDD_OK;
     REQUIRE(raw && tile_counts, "mdd_jsonl_count_lines: NULL buffer");
     REQUIRE((reinterpret_cast<uintptr_t>(raw) & 3u) == 0, "mdd_jsonl_count_lines: raw must be 4-byte aligned");

@@ -389,6 +389,7 @@ def read_jsonl_batch_device(eng, paths, content_field: str, id_field=None, on_er
       ids       list per row (None without id_field);  cand  int64: row index of every document that will be hashed
       text / offsets / text_bytes   DEVICE tensors: packed utf-8 (padded) and int64 offsets of those documents, in row order
       n_bad     int64 per file: lines that are not JSON objects
+      line_starts  per file: int64 byte offset of every line start + the file size (None when the batch holds a "\\r")
       host_files  indices of files the device did not take (gzip): read them with read_jsonl_shard
     or None when nothing can be done on the device for this batch (field names that need JSON escaping, a lone "\\r"
     somewhere in the batch: text-mode line semantics) -- then every file goes to read_jsonl_shard.
@@ -459,7 +460,17 @@ def read_jsonl_batch_device(eng, paths, content_field: str, id_field=None, on_er
     else:
         cand_lines = ok_lines
     fo_rows = file_of_line(rows)
-    return {"file_of": fo_rows, "line_no": (rows - first_line[fo_rows]).astype(np.uint64), "ids": ids,
+    # byte offset of every line start inside its file (+ the file size as the last entry), for byte-range copies of the
+    # surviving lines (ZH-5); only when the batch holds no "\r" at all (else ZH-5's text-mode rewrite changes bytes)
+    line_starts = None
+    if x["n_cr"] == 0:
+        line_starts = []
+        ends = np.append(first_line[1:], x["n_lines"])
+        for k in range(len(paths)):
+            size_k = int(starts[k + 1] - starts[k] - 1)
+            ls = lb[first_line[k]:ends[k]] - starts[k]
+            line_starts.append(np.append(ls[ls < size_k], size_k))
+    return {"file_of": fo_rows, "line_starts": line_starts, "line_no": (rows - first_line[fo_rows]).astype(np.uint64), "ids": ids,
             "cand": row_of_line[cand_lines], "text": text, "offsets": offsets, "text_bytes": total, "n_bad": n_bad,
             "host_files": np.flatnonzero(is_gz).tolist(), "device_lines": int(len(ok_lines)), "fallback_lines": int(len(fb))}
 

@@ -543,7 +543,7 @@ class Engine:
         for the lines the device can vouch for).  raw: uint8 device tensor of capacity >= padded_size(raw_bytes).
         Returns a dict:
           n_lines, status (uint8 host array per physical line: 0 OK, 1 no content, 2 fallback -- run json.loads on it --, 3 blank),
-          line_begin (uint64 host array [n_lines+1]), lone_cr (lone "\\r" bytes: a text-mode reader splits there),
+          line_begin (uint64 host array [n_lines+1]), lone_cr (lone "\\r" bytes: a text-mode reader splits there), n_cr (all "\\r"),
           text / offsets (device: packed decoded content of the OK lines, int64 [n_ok+1]), ok_lines (int64 host array),
           id_kind / id_beg / id_end (host arrays per line; None without id_field).
         None when the field names need JSON escaping or exceed 64 bytes (MDD_ERR_UNSUPPORTED: use the host reader)."""
@@ -551,9 +551,9 @@ class Engine:
         raw_bytes = int(raw_bytes)
         n_tiles = max(1, -(-raw_bytes // self.JSONL_TILE))
         tile_counts = torch.zeros(n_tiles, dtype=torch.int32, device=self.device)
-        totals = torch.zeros(2, dtype=torch.int64, device=self.device)
+        totals = torch.zeros(3, dtype=torch.int64, device=self.device)
         _lib.check(self.L.mdd_jsonl_count_lines(self.ctx, _ptr(raw), raw_bytes, _ptr(tile_counts), _ptr(totals)), "mdd_jsonl_count_lines")
-        n_nl, lone_cr = (int(x) for x in totals.cpu().tolist())
+        n_nl, lone_cr, n_cr = (int(x) for x in totals.cpu().tolist())
         last_open = raw_bytes > 0 and int(raw[raw_bytes - 1].item()) != 10
         n_lines = n_nl + (1 if last_open else 0)
         tile_base = torch.cumsum(tile_counts.to(torch.int64), 0) - tile_counts      # exclusive prefix (plumbing)
@@ -583,7 +583,7 @@ class Engine:
         ok = torch.nonzero(status == 0).flatten()
         offsets = torch.cat([out_offs[:-1][ok], out_offs[-1:]])
         res = {"n_lines": n_lines, "status": status.cpu().numpy(), "line_begin": line_begin.cpu().numpy().view(np.uint64),
-               "lone_cr": lone_cr, "text": text, "offsets": offsets, "text_bytes": total, "ok_lines": ok.cpu().numpy(),
+               "lone_cr": lone_cr, "n_cr": n_cr, "text": text, "offsets": offsets, "text_bytes": total, "ok_lines": ok.cpu().numpy(),
                "id_kind": None, "id_beg": None, "id_end": None}
         if id_field:
             res.update(id_kind=idk.cpu().numpy(), id_beg=idb.cpu().numpy().view(np.uint64), id_end=ide.cpu().numpy().view(np.uint64))
