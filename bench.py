@@ -227,6 +227,36 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
     return out
 
 
+def gpu_locality(index: int) -> dict:
+    """NUMA placement facts for the streamed-input figures: the GPU's PCI address, its NUMA node and
+    local CPUs from sysfs, and the CPUs this process may run on."""
+    import torch
+    info = {"allowed_cpus": len(os.sched_getaffinity(0))}
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        info["pci"] = bdf
+        base = "/sys/bus/pci/devices/" + bdf
+        info["gpu_numa_node"] = int(open(base + "/numa_node").read())
+        info["gpu_local_cpulist"] = open(base + "/local_cpulist").read().strip()
+        nodes = [d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]
+        info["numa_nodes"] = len(nodes)
+    except Exception as e:      # noqa: BLE001 -- diagnostics only
+        info["error"] = repr(e)
+    return info
+
+
+def cpus_of(cpulist: str):
+    out = set()
+    for part in cpulist.split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out.update(range(int(a), int(b) + 1))
+        elif part.strip():
+            out.add(int(part))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,16 +356,48 @@ def main():
     pinned = None
     if rank == 0 and world == 1 and text_bytes < (8 << 30) and not args.no_pcie:
         try:
+            stage = torch.empty_like(text)
+
+            def h2d_time(buf):
+                best = None
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    stage.copy_(buf, non_blocking=True)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
+                return best
+
+            # Where the pinned buffer lives matters (58 vs 63 ms between boxes): it is allocated twice,
+            # once wherever this thread happens to run and once with the thread confined to the GPU's local CPUs (sysfs
+            # local_cpulist) while the pages are allocated and first touched; the faster one carries the streamed passes
+            # and both H2D times are reported.
+            locality = gpu_locality(dev.index if dev.index is not None else 0)
             host = torch.empty(text.numel(), dtype=torch.uint8, pin_memory=True)
             host.copy_(text)
-            stage = torch.empty_like(text)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            stage.copy_(host, non_blocking=True)
-            e1.record()
-            torch.cuda.synchronize()
-            h2d_ms = e0.elapsed_time(e1)
+            h2d_default = h2d_time(host)
+            h2d_local = None
+            try:
+                allowed = os.sched_getaffinity(0)
+                local = cpus_of(locality.get("gpu_local_cpulist", "")) & allowed
+                if local and local != allowed:
+                    os.sched_setaffinity(0, local)
+                    try:
+                        host2 = torch.empty(text.numel(), dtype=torch.uint8, pin_memory=True)
+                        host2.copy_(text)
+                    finally:
+                        os.sched_setaffinity(0, allowed)
+                    h2d_local = h2d_time(host2)
+                    if h2d_local < h2d_default:
+                        host = host2
+                    del host2
+                locality["local_cpus_allowed"] = len(local)
+            except Exception as e:      # noqa: BLE001 -- diagnostics only
+                locality["affinity_error"] = repr(e)
+            h2d_ms = min(h2d_default, h2d_local) if h2d_local is not None else h2d_default
+            locality.update(h2d_ms_default_placement=h2d_default, h2d_ms_gpu_local_placement=h2d_local)
             del stage
             # SURVEY 8(d)'s region: packed text + offsets in PINNED HOST memory -> removed mask on the host.  ONE
             # signature launch hashes the documents while the text is still arriving over PCIe
@@ -368,7 +430,8 @@ def main():
                 torch.cuda.synchronize()
                 pin_ms.append((time.perf_counter() - tp) * 1e3)
                 pin_sig_ms.append(e0.elapsed_time(ev))
-            pinned = {"ms_per_pass": min(pin_ms), "docs_per_s": n_local / (min(pin_ms) * 1e-3),
+            pinned = {"ms_per_pass": min(pin_ms), "ms_all_passes": pin_ms, "signatures_ms_all_passes": pin_sig_ms, "locality": locality,
+                      "docs_per_s": n_local / (min(pin_ms) * 1e-3),
                       "text_gb_per_s": text_bytes / (min(pin_ms) * 1e6), "signatures_ms": min(pin_sig_ms),
                       "kernel_wait_wave_ms": eng.stream_wait_ms(), "n_removed": int(removed_pin.sum().item()),
                       "region": "packed utf-8 + offsets in pinned host memory -> removed mask in pinned host memory (SURVEY 8(d)); "
