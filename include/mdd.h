@@ -330,11 +330,28 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *            ws            u64[ws_words], ws_words >= MDD_SUBSTR_SORTED_WS_WORDS (89 MiB)
  *          part / n_parts as for `mark` (windows are split by content key; part 0 clears dup).  An entry array that is
  *          too small, or more than 768 distinct windows in one leaf (or one 4096-window slice of a big leaf), is
- *          counted and reported by mdd_substr_check: redo with more parts, or use `mark`. */
+ *          counted and reported by mdd_substr_check: redo with more parts, or use `mark`.
+ *          cand (round 3; NULL = every window takes part): u8[text_bytes] from mdd_substr_candidates -- windows whose
+ *          flag is 0 are skipped.  The marks are the same with and without it; ent_cap then only has to hold the
+ *          candidate windows of the pass.
+ *   candidates: the filter in front of mark_sorted (same reference lines: it decides nothing, it only proves windows
+ *          unique).  A window that occurs twice holds the same 32-byte k-grams at the same offsets in both copies, so
+ *          it can only take part in a group when the k-gram its bytes select -- the one with the smallest hash among
+ *          those starting in its first 19 bytes, leftmost on ties -- occurs twice in the corpus.  The selected k-grams
+ *          ("anchors", one per ~10 windows) are sorted and grouped like windows (same workspaces; ent_cap >=
+ *          max(windows / 4, (text_bytes + 71) / 8) + the slack above is ample: anchors beyond it switch the filter
+ *          off, they do not fail the call), and cand[p] = 1 for every byte position p with a repeated anchor in
+ *          [p, p + 18].  *n_cand (DEVICE) = number of flagged positions, an upper bound of the windows mark_sorted
+ *          will sort.  Asynchronous.  50 <= window <= 128 (a window of w code points has >= w bytes; below 50 bytes
+ *          the selection does not fit: call mark_sorted with cand = NULL); cand 8-byte aligned.  On C2 (1 M documents,
+ *          15 % near-copies) 28 % of the windows remain and the stage takes 61 instead of 80 ms. */
 #define MDD_SUBSTR_SORTED_WS_WORDS 11672587ull
 int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                            int window, int part, int n_parts, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap,
-                           uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup);
+                           uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup, const uint8_t* cand);
+int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                          int window, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap, uint16_t* d1_ws, uint64_t* ws,
+                          uint64_t ws_words, uint8_t* cand, uint64_t* n_cand);
 /*   check: mark is asynchronous and cannot validate tab_size against the (device-side) number of windows.  A window
  *          that finds neither its content nor a free slot is counted on the device; mdd_substr_check synchronises
  *          the stream, stores that count in *n_overflow_host (HOST, may be NULL), clears it and returns

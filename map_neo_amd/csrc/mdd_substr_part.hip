@@ -15,6 +15,18 @@
 //             the slices meet in a small global table (bigleaf_kernel); more than LEAF_SLOTS * 3/4 DISTINCT windows in one
 //             round (hash adversary) raise the overflow count that mdd_substr_check reports.
 // Equal 64-bit keys land in the same leaf, so every pair of identical windows meets in one LDS table.
+//
+// CANDIDATE FILTER (mdd_substr_candidates, round 3).  Most windows of a corpus occur once; sorting them all only to
+// find that out is what the method above spends its time on.  A window that occurs twice contains, at the same place
+// in both copies, every k-gram of its bytes -- so a window can only be a repeat (or the first of a repeated content)
+// when the k-gram its content SELECTS occurs twice in the corpus.  The selection is a minimizer: of the 19 32-byte
+// k-grams that start in the window's first 19 bytes (a window of >= 50 code points has >= 50 bytes, so all of them lie
+// inside it) the one with the smallest hash, leftmost on ties -- a function of the window's bytes alone.  Consecutive
+// windows mostly select the same k-gram: one ANCHOR per ~10 windows.  The anchors (10 % of the entries) go through the
+// same two-level sort; a leaf pass flags every anchor whose key occurs twice (key equality only: a false match merely
+// lets windows through); a streaming pass turns anchor flags into window flags (cand[p] = any flagged anchor in
+// [p, p + 18]: a superset of "p's own anchor is flagged").  emit_kernel then skips every window whose flag is clear.
+// Everything the filter does errs on the side of keeping a window, so the marks are those of the unfiltered method.
 #include "mdd_shingle.h"
 
 namespace {
@@ -108,6 +120,7 @@ struct EmitArgs {
     unsigned long long* overflow;
     uint32_t part, n_parts;
     uint32_t batch_shift;  // a claim on the work counter takes (items left) >> batch_shift items, clamped to [1, 16]
+    const uint8_t* cand;   // candidate flag per byte position (mdd_substr_candidates) or NULL: every window takes part
 };
 
 // persistent waves pulling documents (then queued segments of long documents) from one counter, four waves per workgroup
@@ -163,6 +176,8 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                            const uint32_t sb = s - boff;
                            // SUB:38 range(len(text) - duplicate_len): the window that ends with the document is never hashed
                            bool on = lane < nvalid && sb + L < len;
+                           // candidate filter: a window whose selected k-gram occurs once in the corpus occurs once itself
+                           if (A.cand && on) on = A.cand[beg + sb] != 0;
                            uint64_t key = 0;
                            if (on) {
                                // (selecting the pass from a cheap hash of the window's first bytes BEFORE the key was tried:
@@ -824,28 +839,483 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
 }
 
+
+// ---- candidate filter: anchors ------------------------------------------------------------------------------------
+constexpr uint32_t AN_KG = 32;                        // bytes of an anchor k-gram
+constexpr uint32_t AN_SPAN = 19;                      // k-gram positions a window selects from: its first 19 byte offsets
+constexpr uint32_t AN_MINWIN = AN_KG + AN_SPAN - 1;   // = 50: the smallest window (in bytes) the selection fits into
+constexpr uint32_t AN_LANES = 50;                     // lanes of a step whose 4 positions get a window minimum: their windows reach
+                                                      // position 4 * 49 + 3 + 18 = 217 (lane 54), whose k-gram ends in lane 62's dword
+static_assert(AN_MINWIN == 50, "mdd_substr_candidates: the filter is defined for windows of at least 50 code points");
+constexpr uint32_t AN_C0 = 0x9E3779B1u, AN_C1 = 0x85EBCA77u, AN_C2 = 0xC2B2AE3Du, AN_C3 = 0x27D4EB2Fu;
+
+// lane l reads x of lane l + n (the top n lanes read the bottom ones: their positions are never used)
+__device__ __forceinline__ uint32_t lane_up(uint32_t x, uint32_t lane, uint32_t n) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + n) & 63u) << 2), (int)x);
+}
+// 64-bit key of the 32 bytes whose dwords are w[0..7]: two multiply-with-carry chains over the even and the odd dwords,
+// one v_xor + one v_mad_u64_u32 per dword.  Any function of the BYTES would do for exactness; this one is cheap.
+__device__ __forceinline__ uint64_t anchor_key(const uint32_t (&w)[8]) {
+    uint64_t a = (uint64_t)(w[0] ^ 0x243F6A88u) * AN_C0 + 0x13198A2E03707344ull;
+    uint64_t b = (uint64_t)(w[1] ^ 0xA4093822u) * AN_C1 + 0x299F31D0082EFA98ull;
+    a = (uint64_t)((uint32_t)a ^ w[2]) * AN_C1 + (a >> 32);
+    b = (uint64_t)((uint32_t)b ^ w[3]) * AN_C0 + (b >> 32);
+    a = (uint64_t)((uint32_t)a ^ w[4]) * AN_C2 + (a >> 32);
+    b = (uint64_t)((uint32_t)b ^ w[5]) * AN_C3 + (b >> 32);
+    a = (uint64_t)((uint32_t)a ^ w[6]) * AN_C3 + (a >> 32);
+    b = (uint64_t)((uint32_t)b ^ w[7]) * AN_C2 + (b >> 32);
+    const uint64_t u = a ^ ((b << 32) | (b >> 32));
+    return (uint64_t)(uint32_t)u * AN_C0 + (uint64_t)(uint32_t)(u >> 32) * 0x9FB21C651E98DF25ull;
+}
+// what is sorted: [d2:11 | tag:17 | pos:36] like a window entry; d1 has 8 bits here (256 partitions x 2048 = 2^19 leaves of
+// ~400 anchors).  The ORDER among a window's k-grams uses bits 31..8 of the key, so d1 / d2 / tag avoid the top of the low
+// half (anchors are minima: those bits are mostly zero).
+__device__ __forceinline__ uint32_t anchor_d1(uint64_t key) { return (uint32_t)(key >> 56); }
+__device__ __forceinline__ uint64_t anchor_entry(uint64_t key, uint64_t pos) {
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    const uint64_t d2tag = ((uint64_t)(hi & 0x00FFFFFFu) << 4) | ((lo >> 8) & 0xFu);  // 24 + 4 = 11 + 17 bits
+    return (d2tag << POS_BITS) | pos;
+}
+
+struct AnchorArgs {
+    const uint8_t* text;
+    uint64_t text_bytes;
+    const uint64_t* offsets;
+    uint64_t n_docs;
+    uint32_t seg_bytes;
+    const uint64_t* items;
+    const uint64_t* n_items;
+    uint64_t max_items;
+    unsigned long long* work_counter;
+    uint64_t* ent;
+    uint16_t* d1;
+    uint64_t ent_cap;
+    unsigned long long* n_ent;
+    unsigned int* hist1;
+    unsigned long long* overflow;  // anchors that found no room: the filter then lets every window through (smear_kernel)
+    uint32_t batch_shift;
+};
+
+// One wave per document (or segment of a long one), persistent, batched claims -- the skeleton of emit_kernel.  A step
+// covers 64 aligned dwords of the text: lane l owns the 4 byte positions of dword l.  It gets the 8 following dwords from
+// the lanes above (so a step reads its 256 bytes once), hashes the four 32-byte k-grams that start in its dword, and the
+// window minimum over 19 positions follows from in-lane prefix / suffix minima and the whole-dword minima of lanes
+// l+1 .. l+5.  The low byte of a packed hash is the position inside the step, so the minimum IS the argmin, leftmost on
+// ties.  Window p emits its anchor when it differs from window p-1's (argmin positions only move forward), through a
+// flag byte in LDS that the anchor's own lane -- which holds its key -- picks up.  Steps advance by 50 lanes.
+__global__ void __launch_bounds__(64 * EMIT_WAVES) anchor_kernel(AnchorArgs A) {
+    __shared__ uint32_t flag_all[EMIT_WAVES][64];
+    __shared__ unsigned int h1[BINS1];
+    uint32_t* flags = flag_all[threadIdx.x >> 6];
+    const uint32_t lane = lane_id();
+    for (int i = threadIdx.x; i < BINS1; i += 64 * EMIT_WAVES) h1[i] = 0;
+    __syncthreads();
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(A.text);
+    const uint64_t extra = *A.n_items;
+    const uint64_t total = A.n_docs + (extra < A.max_items ? extra : A.max_items);
+    auto fetch = [&](uint32_t n) -> uint64_t {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(A.work_counter, (unsigned long long)n);
+        uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t chunk_pos = 0, chunk_end = 0;
+    uint64_t item = 0, batch_end = 0;
+    for (;; item++) {
+        if (item >= batch_end) {
+            const uint64_t want = (total > item ? total - item : 0) >> A.batch_shift;
+            const uint32_t n = want < 1u ? 1u : (want > 16u ? 16u : (uint32_t)want);
+            item = fetch(n);
+            if (item >= total) break;
+            batch_end = item + n < total ? item + n : total;
+        }
+        uint64_t d = item;
+        uint32_t seg = 0;
+        if (d >= A.n_docs) {
+            uint64_t it = A.items[d - A.n_docs];
+            d = it >> 24;
+            seg = (uint32_t)it & 0xFFFFFFu;
+        }
+        uint64_t beg, end;
+        doc_range(A.offsets, d, A.text_bytes, beg, end);
+        const uint64_t len = end - beg;
+        if (len < AN_MINWIN) continue;
+        // window starts of this item: absolute byte positions [lo_abs, hi_abs); every window of >= 50 code points that the
+        // stage hashes starts at a p with p + 50 < end, so "p + 50 <= end" takes a superset (other code-point starts,
+        // continuation bytes): more anchors than needed, never fewer
+        uint64_t seg_beg = 0, seg_end = len;
+        if (len > A.seg_bytes) {
+            seg_beg = (uint64_t)seg * A.seg_bytes;
+            seg_end = seg_beg + A.seg_bytes < len ? seg_beg + A.seg_bytes : len;
+        }
+        const uint64_t lo_abs = beg + seg_beg;
+        const uint64_t hi_abs = beg + (seg_end < len - (AN_MINWIN - 1) ? seg_end : len - (AN_MINWIN - 1));
+        if (lo_abs >= hi_abs) continue;
+        const uint64_t last_dw = (end - 1) >> 2;  // the document's last dword: lanes past it re-read it (their positions are not used)
+        uint64_t a_prev = ~0ull;                  // anchor of the previous step's last window (absolute position)
+        uint32_t d_next;  // the next step's dword is requested before this step is worked on
+        {
+            const uint64_t i0 = (lo_abs >> 2) + lane;
+            d_next = tw[i0 < last_dw ? i0 : last_dw];
+        }
+        for (uint64_t base_dw = lo_abs >> 2; 4 * base_dw < hi_abs; base_dw += AN_LANES) {
+            const uint64_t my_dw = base_dw + lane;
+            uint32_t D[9];
+            D[0] = d_next;
+            {
+                const uint64_t i1 = my_dw + AN_LANES;
+                d_next = tw[i1 < last_dw ? i1 : last_dw];
+            }
+#pragma unroll
+            for (uint32_t k = 1; k <= 8; k++) D[k] = lane_up(D[0], lane, k);
+            uint32_t keylo[4], keyhi[4], pk[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                uint32_t w[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) w[k] = j ? __builtin_amdgcn_alignbyte(D[k + 1], D[k], j) : D[k];
+                const uint64_t key = anchor_key(w);
+                keylo[j] = (uint32_t)key;
+                keyhi[j] = (uint32_t)(key >> 32);
+                pk[j] = (keylo[j] & 0xFFFFFF00u) | (4u * lane + j);
+            }
+            // suffix minima s_j = min(pk[j..3]), prefix minima p_j = min(pk[0..j])
+            const uint32_t s3 = pk[3], s2 = pk[2] < s3 ? pk[2] : s3, s1 = pk[1] < s2 ? pk[1] : s2, s0 = pk[0] < s1 ? pk[0] : s1;
+            const uint32_t p1 = pk[0] < pk[1] ? pk[0] : pk[1], p2 = p1 < pk[2] ? p1 : pk[2];
+            const uint32_t M1 = lane_up(s0, lane, 1), M2 = lane_up(s0, lane, 2), M3 = lane_up(s0, lane, 3), M4 = lane_up(s0, lane, 4);
+            const uint32_t P2_4 = lane_up(p2, lane, 4), P0_5 = lane_up(pk[0], lane, 5), P1_5 = lane_up(p1, lane, 5);
+            uint32_t Q = M1 < M2 ? M1 : M2;
+            Q = Q < M3 ? Q : M3;
+            const uint32_t QQ = Q < M4 ? Q : M4;
+            // window of position 4l + j: positions 4l + j .. 4l + j + 18
+            uint32_t win[4];
+            win[0] = s0 < Q ? s0 : Q;
+            win[0] = win[0] < P2_4 ? win[0] : P2_4;  // l+4: positions 0..2
+            win[1] = s1 < QQ ? s1 : QQ;              // l+4: positions 0..3
+            win[2] = s2 < QQ ? s2 : QQ;
+            win[2] = win[2] < P0_5 ? win[2] : P0_5;  // l+5: position 0
+            win[3] = s3 < QQ ? s3 : QQ;
+            win[3] = win[3] < P1_5 ? win[3] : P1_5;  // l+5: positions 0..1
+            uint32_t code[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) code[j] = win[j] & 0xFFu;
+            // the anchor of the window before this lane's first one
+            const uint32_t carry_code = a_prev == ~0ull ? 0xFFFFFFFFu : (uint32_t)(a_prev - 4 * base_dw);  // (a_prev >= 4 * base_dw - 1 ... any mismatch is harmless)
+            uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 63u) & 63u) << 2), (int)code[3]);
+            if (lane == 0) prev = carry_code;
+            flags[lane] = 0;
+            lds_sync();
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint64_t p_abs = 4 * my_dw + j;
+                const bool valid = lane < AN_LANES && p_abs >= lo_abs && p_abs < hi_abs;
+                if (valid && (p_abs == lo_abs || code[j] != prev)) reinterpret_cast<uint8_t*>(flags)[code[j]] = 1;
+                prev = code[j];
+            }
+            lds_sync();
+            const uint32_t F = flags[lane];  // byte j set: position 4 * lane + j is a new anchor
+            lds_sync();
+            a_prev = 4 * base_dw + __builtin_amdgcn_readlane(code[3], AN_LANES - 1);
+            const uint32_t cnt = (uint32_t)__builtin_popcount(F);
+            const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+            const uint32_t tot = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+            if (tot == 0) continue;
+            if (chunk_pos + tot > chunk_end) {  // void the rest of the chunk (< 256 entries) and take a new one
+                for (uint64_t i = chunk_pos + lane; i < chunk_end && i < A.ent_cap; i += 64) {
+                    A.ent[i] = ENT_INVALID;
+                    A.d1[i] = D1_INVALID;
+                }
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(A.n_ent, (unsigned long long)EMIT_CHUNK);
+                uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+                chunk_pos = ((uint64_t)hi << 32) | lo;
+                chunk_end = chunk_pos + EMIT_CHUNK;
+            }
+            uint64_t o = chunk_pos + below(b0) + 2u * below(b1) + 4u * below(b2);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (F & (0xFFu << (8 * j))) {
+                    const uint64_t key = ((uint64_t)keyhi[j] << 32) | keylo[j];
+                    if (o < A.ent_cap) {
+                        A.ent[o] = anchor_entry(key, 4 * my_dw + j);
+                        A.d1[o] = (uint16_t)anchor_d1(key);
+                        atomicAdd(&h1[anchor_d1(key)], 1u);
+                    } else {
+                        atomicAdd(A.overflow, 1ull);
+                    }
+                    o++;
+                }
+            chunk_pos += tot;
+        }
+    }
+    for (uint64_t i = chunk_pos + lane; i < chunk_end && i < A.ent_cap; i += 64) {
+        A.ent[i] = ENT_INVALID;
+        A.d1[i] = D1_INVALID;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS1; i += 64 * EMIT_WAVES)
+        if (h1[i]) atomicAdd(&A.hist1[i], h1[i]);
+}
+
+// One wave per leaf of anchors: flag every anchor whose (d2, tag) occurs twice in the leaf.  Key equality only -- a false
+// match lets a few windows through, nothing else -- so a leaf too big for the table is flagged whole.
+constexpr uint32_t ALEAF_CH = 12;  // 768 anchors per leaf at most go through the table (1024 slots)
+__global__ void __launch_bounds__(64) anchor_leaf_kernel(const uint64_t* __restrict__ ent, const uint64_t* __restrict__ off2, uint32_t n_leaves,
+                                                         uint8_t* flag, uint64_t text_bytes) {
+    __shared__ unsigned long long tab[LEAF_SLOTS];
+    const uint32_t lane = lane_id();
+    for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
+        const uint64_t lo = off2[leaf], hi = off2[leaf + 1];
+        if (hi - lo < 2) continue;
+        if (hi - lo > 64 * ALEAF_CH) {
+            for (uint64_t i = lo + lane; i < hi; i += 64) {
+                const uint64_t pos = ent[i] & POS_M;
+                if (pos < text_bytes) flag[pos] = 1;
+            }
+            continue;
+        }
+        unsigned long long e[ALEAF_CH];
+#pragma unroll
+        for (uint32_t k = 0; k < ALEAF_CH; k++) {
+            const uint64_t i = lo + (uint64_t)k * 64 + lane;
+            e[k] = i < hi ? ent[i] : ENT_INVALID;
+        }
+#pragma unroll
+        for (int i = 0; i < LEAF_SLOTS / 64; i++) tab[i * 64 + lane] = ENT_INVALID;
+        lds_sync();
+#pragma unroll 1
+        for (uint32_t k = 0; k < ALEAF_CH; k++) {
+            const unsigned long long val = e[0];
+#pragma unroll
+            for (uint32_t j = 0; j + 1 < ALEAF_CH; j++) e[j] = e[j + 1];
+            e[ALEAF_CH - 1] = ENT_INVALID;
+            if (val == ENT_INVALID) continue;
+            uint32_t slot = leaf_home(val);
+            for (uint32_t probe = 0; probe < LEAF_SLOTS; probe++) {
+                const unsigned long long cur = atomicCAS(&tab[slot], ENT_INVALID, val);
+                if (cur == ENT_INVALID) break;
+                if ((cur >> POS_BITS) == (val >> POS_BITS)) {
+                    const uint64_t p = val & POS_M, q = cur & POS_M;
+                    if (p < text_bytes) flag[p] = 1;
+                    if (q < text_bytes) flag[q] = 1;
+                    break;
+                }
+                slot = (slot + 1) & (LEAF_SLOTS - 1);
+            }
+        }
+        lds_sync();
+    }
+}
+
+// cand[p] = 1 when an anchor in [p, p + 18] is flagged (window p selects one of these positions; flagging all of them is
+// a superset).  8 positions per thread; flag has 32 readable zero bytes past text_bytes.  *overflow != 0 (anchors without
+// room in the entry array): every position is a candidate.  *n_cand += candidate positions.
+__global__ void __launch_bounds__(256) smear_kernel(const uint8_t* __restrict__ flag, uint64_t text_bytes, uint8_t* __restrict__ cand,
+                                                    unsigned long long* n_cand, const unsigned long long* overflow) {
+    __shared__ unsigned int wsum[4];
+    const bool all = *overflow != 0;
+    uint32_t c = 0;
+    // (grid-stride: one atomic per workgroup at the end -- same-address atomics retire at ~11 ns each, a counter update per
+    // wave of a thread-per-8-bytes launch took 43 ms on 2 GB)
+    for (uint64_t q = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; q < text_bytes; q += (uint64_t)gridDim.x * 2048) {
+        uint64_t out = 0;
+        const uint64_t* f = reinterpret_cast<const uint64_t*>(flag + q);
+        const uint64_t w0 = f[0], w1 = f[1], w2 = f[2], w3 = f[3];
+        if (all) {
+            out = 0x0101010101010101ull;
+        } else if (w0 | w1 | w2 | w3) {
+            // F = w3:w2:w1:w0 (little endian bytes); OR over n consecutive bytes by doubling: r2, r4, r8, r16; 19 = 16 + overlap of r4 at +15
+            auto shr = [](uint64_t lo, uint64_t hi, int bytes) { return (lo >> (8 * bytes)) | (hi << (64 - 8 * bytes)); };  // bytes in 1..7
+            const uint64_t a0 = w0 | shr(w0, w1, 1), a1 = w1 | shr(w1, w2, 1), a2 = w2 | shr(w2, w3, 1), a3 = w3 | (w3 >> 8);   // r2
+            const uint64_t b0 = a0 | shr(a0, a1, 2), b1 = a1 | shr(a1, a2, 2), b2 = a2 | shr(a2, a3, 2);                          // r4 (words 0..2; word 2 lacks bytes >= 32: not needed below byte 26)
+            const uint64_t c0 = b0 | shr(b0, b1, 4), c1 = b1 | shr(b1, b2, 4);                                                    // r8
+            const uint64_t d0 = c0 | c1;                                                                                          // r16 = r8 | r8 >> 64 bits
+            out = d0 | shr(b1, b2, 7);                                                                                            // r4 at byte offset 15
+        }
+        if (q + 8 <= text_bytes) {
+            *reinterpret_cast<uint64_t*>(cand + q) = out;
+        } else {
+            for (uint64_t k = 0; q + k < text_bytes; k++) cand[q + k] = (uint8_t)(out >> (8 * k));
+            out &= ~0ull >> (8 * (8 - (text_bytes - q)));
+        }
+        c += (uint32_t)__builtin_popcountll(out);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && (wsum[0] | wsum[1] | wsum[2] | wsum[3]))
+        atomicAdd(n_cand, (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+// The caller's workspace `ws` of the sorted method, carved (u64 words): off1[BINS1+1] | cursor1[BINS1] | off2[n_leaves+1] |
+// cursor2[n_leaves] | hist1 (u32 x BINS1) | cnt2 (u32 x n_leaves) | counters[8] | scan scratch[1024] | tile_off (u32 x (BINS1+2)) |
+// big_list (u32 x BIG_LIST_CAP) | big_tab[2^BIG_TAB_BITS]
+struct SortWs {
+    static constexpr uint64_t NL = (uint64_t)BINS1 * BINS2;
+    static constexpr uint64_t WORDS =
+        (BINS1 + 1) + BINS1 + (NL + 1) + NL + BINS1 / 2 + NL / 2 + 8 + 1024 + (BINS1 + 2) / 2 + BIG_LIST_CAP / 2 + (1ull << BIG_TAB_BITS);
+    uint64_t* off1;
+    unsigned long long* cursor1;
+    uint64_t* off2;
+    unsigned long long* cursor2;
+    unsigned int* hist1;
+    unsigned int* cnt2;
+    unsigned long long* counters;  // [0] entries handed out, [1..5] MDD_LEAF_PROF, [6] big leaves queued (u32), [7] anchors without room
+    uint64_t* sums;
+    unsigned int* tile_off;
+    unsigned int* big_list;
+    unsigned long long* big_tab;
+    explicit SortWs(uint64_t* ws) {
+        off1 = ws;
+        cursor1 = reinterpret_cast<unsigned long long*>(off1 + BINS1 + 1);
+        off2 = reinterpret_cast<uint64_t*>(cursor1 + BINS1);
+        cursor2 = reinterpret_cast<unsigned long long*>(off2 + NL + 1);
+        hist1 = reinterpret_cast<unsigned int*>(cursor2 + NL);
+        cnt2 = hist1 + BINS1;
+        counters = reinterpret_cast<unsigned long long*>(cnt2 + NL);
+        sums = reinterpret_cast<uint64_t*>(counters + 8);
+        tile_off = reinterpret_cast<unsigned int*>(sums + 1024);
+        big_list = tile_off + BINS1 + 2;
+        big_tab = reinterpret_cast<unsigned long long*>(big_list + BIG_LIST_CAP);
+    }
+    // clears the histograms and the counters (they are contiguous)
+    int clear(hipStream_t st) const {
+        HIP_TRY(hipMemsetAsync(hist1, 0, (BINS1 + NL) * sizeof(unsigned int) + 8 * sizeof(uint64_t), st));
+        return MDD_OK;
+    }
+};
+static_assert(SortWs::WORDS == MDD_SUBSTR_SORTED_WS_WORDS, "include/mdd.h: MDD_SUBSTR_SORTED_WS_WORDS");
+
+// the entries of ent_a (level-1 digits in d1_ws, their histogram in W.hist1, their number in W.counters[0]) sorted into
+// leaves: afterwards ent_a holds them leaf by leaf and W.off2[leaf .. leaf + 1] is a leaf's range; ent_b is scratch
+int sort_into_leaves(hipStream_t st, const SortWs& W, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap, uint16_t* d1_ws) {
+    // ---- level 1
+    {
+        int rc = exclusive_scan(st, W.hist1, (uint64_t)BINS1, W.off1, W.sums);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(W.cursor1, W.off1, BINS1 * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(scatter_kernel<1>, dim3((unsigned)((ent_cap + TILE1 - 1) / TILE1)), dim3(SC_THREADS), 0, st, ent_a, d1_ws, W.counters, ent_cap,
+                       W.off1, W.tile_off, ent_b, W.cursor1);
+    HIP_TRY(hipGetLastError());
+    // ---- level 2
+    const unsigned max_tiles2 = (unsigned)((ent_cap / TILE2 + BINS1 + XCDS - 1) / XCDS * XCDS);
+    hipLaunchKernelGGL(tile_map_kernel, dim3(1), dim3(1024), 0, st, W.off1, W.tile_off);
+    hipLaunchKernelGGL(count2_kernel, dim3(max_tiles2), dim3(256), 0, st, ent_b, W.off1, W.tile_off, W.cnt2);
+    {
+        int rc = exclusive_scan(st, W.cnt2, SortWs::NL, W.off2, W.sums);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(W.cursor2, W.off2, SortWs::NL * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(scatter_kernel<2>, dim3(max_tiles2), dim3(SC_THREADS), 0, st, ent_b, (const uint16_t*)nullptr, W.counters, ent_cap, W.off1,
+                       W.tile_off, ent_a, W.cursor2);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
+// segment plan shared by the two entry points: long documents are cut into segments queued in the context
+int plan_segments(mdd_ctx* ctx, const char* who, const uint64_t* offsets, uint64_t n_docs, uint64_t text_bytes, uint32_t& seg_bytes,
+                  uint64_t& max_items) {
+    uint64_t seg = ctx->seg_bytes, need = text_bytes / SEG_ITEM_CAP + 1;
+    if (seg < need) seg = need;
+    seg = (seg + 255) / 256 * 256;
+    REQUIRE(seg <= 0xFFFFFF00ull, "%s: text too large for the segment plan", who);
+    max_items = text_bytes / seg;
+    if (max_items > SEG_ITEM_CAP) max_items = SEG_ITEM_CAP;
+    seg_bytes = (uint32_t)seg;
+    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes, seg_bytes,
+                       ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, (uint32_t*)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
+
 }  // namespace
+
+extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
+                                     int window, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap, uint16_t* d1_ws, uint64_t* ws,
+                                     uint64_t ws_words, uint8_t* cand, uint64_t* n_cand) {
+    REQUIRE(ctx, "mdd_substr_candidates: ctx is NULL");
+    REQUIRE(window >= (int)AN_MINWIN && window <= 128, "mdd_substr_candidates: window=%d outside [%u,128] (smaller windows: no filter, pass cand = NULL to mdd_substr_mark_sorted)",
+            window, AN_MINWIN);
+    REQUIRE(text_bytes < (1ULL << POS_BITS), "mdd_substr_candidates: text_bytes must be below 2^36");
+    REQUIRE(n_cand, "mdd_substr_candidates: n_cand is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemsetAsync(n_cand, 0, sizeof(uint64_t), st));
+    if (n_docs == 0 || text_bytes == 0) return MDD_OK;
+    REQUIRE(text && offsets && ent_a && ent_b && d1_ws && ws && cand, "mdd_substr_candidates: NULL buffer");
+    REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_candidates: text must be 4-byte aligned");
+    REQUIRE(ws_words >= SortWs::WORDS, "mdd_substr_candidates: workspace of %llu u64 words needed (MDD_SUBSTR_SORTED_WS_WORDS)",
+            (unsigned long long)SortWs::WORDS);
+    REQUIRE((reinterpret_cast<uintptr_t>(ent_a) & 7u) == 0 && (reinterpret_cast<uintptr_t>(ent_b) & 7u) == 0 &&
+                (reinterpret_cast<uintptr_t>(d1_ws) & 1u) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0 &&
+                (reinterpret_cast<uintptr_t>(cand) & 7u) == 0,
+            "mdd_substr_candidates: ent_a, ent_b, ws, cand must be 8-byte aligned, d1_ws 2-byte aligned");
+    const uint64_t waves = (uint64_t)ctx->cus * 4 * 7;
+    // ent_b doubles as the anchor flags (one byte per text position + 64) once the sort is done with it
+    REQUIRE(ent_cap >= waves * EMIT_CHUNK + TILE1 && ent_cap < (1ULL << 40) && ent_cap >= (text_bytes + 64 + 7) / 8,
+            "mdd_substr_candidates: ent_cap=%llu too small (need max(%llu, (text_bytes + 71) / 8); anchors beyond it only switch the filter off)",
+            (unsigned long long)ent_cap, (unsigned long long)(waves * EMIT_CHUNK + TILE1));
+    const SortWs W(ws);
+    {
+        int rc = W.clear(st);
+        if (rc) return rc;
+    }
+    AnchorArgs E{};
+    E.text = text;
+    E.text_bytes = text_bytes;
+    E.offsets = offsets;
+    E.n_docs = n_docs;
+    uint64_t max_items = 0;
+    {
+        int rc = plan_segments(ctx, "mdd_substr_candidates", offsets, n_docs, text_bytes, E.seg_bytes, max_items);
+        if (rc) return rc;
+    }
+    E.items = ctx->seg_items;
+    E.n_items = ctx->seg_n_items;
+    E.max_items = max_items;
+    E.work_counter = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 1);
+    E.ent = ent_a;
+    E.d1 = d1_ws;
+    E.ent_cap = ent_cap;
+    E.n_ent = W.counters;
+    E.hist1 = W.hist1;
+    E.overflow = W.counters + 7;
+    uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
+    while ((1ull << E.batch_shift) < w * 4) E.batch_shift++;
+    hipLaunchKernelGGL(anchor_kernel, dim3((unsigned)((w + EMIT_WAVES - 1) / EMIT_WAVES)), dim3(64 * EMIT_WAVES), 0, st, E);
+    HIP_TRY(hipGetLastError());
+    {
+        int rc = sort_into_leaves(st, W, ent_a, ent_b, ent_cap, d1_ws);
+        if (rc) return rc;
+    }
+    uint8_t* flag = reinterpret_cast<uint8_t*>(ent_b);
+    HIP_TRY(hipMemsetAsync(flag, 0, text_bytes + 64, st));
+    hipLaunchKernelGGL(anchor_leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, ent_a, W.off2, 256u * (uint32_t)BINS2, flag,
+                       text_bytes);
+    const uint64_t smear_blocks = (text_bytes + 2047) / 2048, smear_cap = (uint64_t)ctx->cus * 16;
+    hipLaunchKernelGGL(smear_kernel, dim3((unsigned)(smear_blocks < smear_cap ? smear_blocks : smear_cap)), dim3(256), 0, st, flag, text_bytes, cand,
+                       reinterpret_cast<unsigned long long*>(n_cand), W.counters + 7);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
 
 extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                                       int window, int part, int n_parts, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap,
-                                      uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup) {
+                                      uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup, const uint8_t* cand) {
     REQUIRE(ctx, "mdd_substr_mark_sorted: ctx is NULL");
     REQUIRE(window >= 1 && window <= 128, "mdd_substr_mark_sorted: window=%d outside [1,128]", window);
     REQUIRE(text_bytes < (1ULL << POS_BITS), "mdd_substr_mark_sorted: text_bytes must be below 2^36 (use mdd_substr_mark beyond)");
     REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "mdd_substr_mark_sorted: part=%d outside [0,%d)", part, n_parts);
+    REQUIRE(!cand || window >= (int)AN_MINWIN, "mdd_substr_mark_sorted: the candidate filter needs window >= %u", AN_MINWIN);
     if (n_docs == 0 || text_bytes == 0) return MDD_OK;
     REQUIRE(text && offsets && ent_a && ent_b && d1_ws && ws && dup, "mdd_substr_mark_sorted: NULL buffer");
     REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_mark_sorted: text must be 4-byte aligned");
-    const uint64_t n_leaves = (uint64_t)BINS1 * BINS2;
-    // workspace layout (u64 words): off1[BINS1+1] | cursor1[BINS1] | off2[n_leaves+1] | cursor2[n_leaves] | hist1 (u32 x BINS1) |
-    // cnt2 (u32 x n_leaves) | counters[8] | scan scratch[1024] | tile_off (u32 x (BINS1+2)) | big_list (u32 x BIG_LIST_CAP) |
-    // big_tab[2^BIG_TAB_BITS]
-    constexpr uint64_t NL = (uint64_t)BINS1 * BINS2;
-    constexpr uint64_t need_words =
-        (BINS1 + 1) + BINS1 + (NL + 1) + NL + BINS1 / 2 + NL / 2 + 8 + 1024 + (BINS1 + 2) / 2 + BIG_LIST_CAP / 2 + (1ull << BIG_TAB_BITS);
-    static_assert(need_words == MDD_SUBSTR_SORTED_WS_WORDS, "include/mdd.h: MDD_SUBSTR_SORTED_WS_WORDS");
-    REQUIRE(ws_words >= need_words, "mdd_substr_mark_sorted: workspace of %llu u64 words needed (MDD_SUBSTR_SORTED_WS_WORDS)",
-            (unsigned long long)need_words);
+    const uint64_t n_leaves = SortWs::NL;
+    REQUIRE(ws_words >= SortWs::WORDS, "mdd_substr_mark_sorted: workspace of %llu u64 words needed (MDD_SUBSTR_SORTED_WS_WORDS)",
+            (unsigned long long)SortWs::WORDS);
     REQUIRE((reinterpret_cast<uintptr_t>(ent_a) & 7u) == 0 && (reinterpret_cast<uintptr_t>(ent_b) & 7u) == 0 &&
                 (reinterpret_cast<uintptr_t>(d1_ws) & 1u) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0,
             "mdd_substr_mark_sorted: ent_a, ent_b, ws must be 8-byte aligned, d1_ws 2-byte aligned");
@@ -854,19 +1324,12 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     REQUIRE(ent_cap >= waves * EMIT_CHUNK + TILE1 && ent_cap < (1ULL << 40),
             "mdd_substr_mark_sorted: ent_cap=%llu too small (need the windows of the pass + %llu)", (unsigned long long)ent_cap,
             (unsigned long long)(waves * EMIT_CHUNK + TILE1));
-    uint64_t* off1 = ws;
-    unsigned long long* cursor1 = reinterpret_cast<unsigned long long*>(off1 + BINS1 + 1);
-    uint64_t* off2 = reinterpret_cast<uint64_t*>(cursor1 + BINS1);
-    unsigned long long* cursor2 = reinterpret_cast<unsigned long long*>(off2 + n_leaves + 1);
-    unsigned int* hist1 = reinterpret_cast<unsigned int*>(cursor2 + n_leaves);
-    unsigned int* cnt2 = hist1 + BINS1;
-    unsigned long long* counters = reinterpret_cast<unsigned long long*>(cnt2 + n_leaves);  // [0] entries handed out
-    uint64_t* sums = reinterpret_cast<uint64_t*>(counters + 8);                              // scratch of the scans (1024 words)
-    unsigned int* tile_off = reinterpret_cast<unsigned int*>(sums + 1024);                   // [BINS1 + 1]
-    unsigned int* big_list = tile_off + BINS1 + 2;
-    unsigned long long* big_tab = reinterpret_cast<unsigned long long*>(big_list + BIG_LIST_CAP);
+    const SortWs W(ws);
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemsetAsync(hist1, 0, (BINS1 + n_leaves) * sizeof(unsigned int) + 8 * sizeof(uint64_t), st));
+    {
+        int rc = W.clear(st);
+        if (rc) return rc;
+    }
     if (part == 0) HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));
     // ---- emit
     EmitArgs E{};
@@ -875,68 +1338,46 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     E.offsets = offsets;
     E.n_docs = n_docs;
     E.window = (uint32_t)window;
-    uint64_t seg = ctx->seg_bytes, need = text_bytes / SEG_ITEM_CAP + 1;
-    if (seg < need) seg = need;
-    seg = (seg + 255) / 256 * 256;
-    REQUIRE(seg <= 0xFFFFFF00ull, "mdd_substr_mark_sorted: text too large for the segment plan");
-    uint64_t max_items = text_bytes / seg;
-    if (max_items > SEG_ITEM_CAP) max_items = SEG_ITEM_CAP;
-    E.seg_bytes = (uint32_t)seg;
+    uint64_t max_items = 0;
+    {
+        int rc = plan_segments(ctx, "mdd_substr_mark_sorted", offsets, n_docs, text_bytes, E.seg_bytes, max_items);
+        if (rc) return rc;
+    }
     E.items = ctx->seg_items;
     E.n_items = ctx->seg_n_items;
     E.max_items = max_items;
     E.work_counter = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 1);
     E.ent = ent_a;
     E.ent_cap = ent_cap;
-    E.n_ent = counters;
-    E.hist1 = hist1;
+    E.n_ent = W.counters;
+    E.hist1 = W.hist1;
     E.overflow = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 2);
     E.part = (uint32_t)part;
     E.n_parts = (uint32_t)n_parts;
     E.d1 = d1_ws;
-    HIP_TRY(hipMemsetAsync(ctx->seg_n_items, 0, 2 * sizeof(uint64_t), st));
-    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, st, offsets, n_docs, text_bytes, E.seg_bytes,
-                       ctx->seg_items, reinterpret_cast<unsigned long long*>(ctx->seg_n_items), max_items, (uint32_t*)nullptr, 0);
-    HIP_TRY(hipGetLastError());
+    E.cand = cand;
     uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
     while ((1ull << E.batch_shift) < w * 4) E.batch_shift++;
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((w + EMIT_WAVES - 1) / EMIT_WAVES)), dim3(64 * EMIT_WAVES), 0, st, E);
     HIP_TRY(hipGetLastError());
-    // ---- level 1
     {
-        int rc = exclusive_scan(st, hist1, (uint64_t)BINS1, off1, sums);
+        int rc = sort_into_leaves(st, W, ent_a, ent_b, ent_cap, d1_ws);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(cursor1, off1, BINS1 * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(scatter_kernel<1>, dim3((unsigned)((ent_cap + TILE1 - 1) / TILE1)), dim3(SC_THREADS), 0, st, ent_a, d1_ws, counters, ent_cap,
-                       off1, tile_off, ent_b, cursor1);
-    HIP_TRY(hipGetLastError());
-    // ---- level 2
-    const unsigned max_tiles2 = (unsigned)((ent_cap / TILE2 + BINS1 + XCDS - 1) / XCDS * XCDS);
-    hipLaunchKernelGGL(tile_map_kernel, dim3(1), dim3(1024), 0, st, off1, tile_off);
-    hipLaunchKernelGGL(count2_kernel, dim3(max_tiles2), dim3(256), 0, st, ent_b, off1, tile_off, cnt2);
-    {
-        int rc = exclusive_scan(st, cnt2, n_leaves, off2, sums);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipMemcpyAsync(cursor2, off2, n_leaves * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(scatter_kernel<2>, dim3(max_tiles2), dim3(SC_THREADS), 0, st, ent_b, (const uint16_t*)nullptr, counters, ent_cap, off1,
-                       tile_off, ent_a, cursor2);
-    HIP_TRY(hipGetLastError());
     // ---- leaves
     LeafArgs L{};
     L.ent = ent_a;
-    L.off2 = off2;
+    L.off2 = W.off2;
     L.n_leaves = n_leaves;
     L.text = text;
     L.text_bytes = text_bytes;
     L.window = (uint32_t)window;
     L.dup = dup;
     L.overflow = reinterpret_cast<unsigned long long*>(ctx->seg_n_items + 2);
-    L.prof = counters + 1;
-    L.n_big = reinterpret_cast<unsigned int*>(counters + 6);  // zeroed with the counters above
-    L.big_list = big_list;
-    L.big_tab = big_tab;
+    L.prof = W.counters + 1;
+    L.n_big = reinterpret_cast<unsigned int*>(W.counters + 6);  // zeroed with the counters above
+    L.big_list = W.big_list;
+    L.big_tab = W.big_tab;
     L.one_round = LEAF_ONE_ROUND;
     L.per_round = LEAF_PER_ROUND;
     if (const char* knob = getenv("MDD_SUBSTR_LEAF_ROUND")) {  // testing: "one_round,per_round" below the defaults forces the multi-round path
@@ -946,7 +1387,7 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
             L.per_round = b;
         }
     }
-    HIP_TRY(hipMemsetAsync(big_tab, 0xFF, sizeof(uint64_t) << BIG_TAB_BITS, st));
+    HIP_TRY(hipMemsetAsync(W.big_tab, 0xFF, sizeof(uint64_t) << BIG_TAB_BITS, st));
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, L);
     hipLaunchKernelGGL(bigleaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, L);  // returns at once when nothing was queued
     HIP_TRY(hipGetLastError());

@@ -94,6 +94,8 @@ class Engine:
         self.table_factor = float(os.environ.get("MDD_TABLE_FACTOR", "2.0"))
         # exact substring dedup: "table" (mdd_substr_mark), "sorted" (mdd_substr_mark_sorted) or "auto" (by size)
         self.substr_method = os.environ.get("MDD_SUBSTR_METHOD", "auto")
+        # sorted method: prove most windows unique first (mdd_substr_candidates); "0" sorts every window (A/B, tests)
+        self.substr_filter = os.environ.get("MDD_SUBSTR_FILTER", "1") != "0"
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -429,24 +431,44 @@ class Engine:
             method = self.substr_method
         if method == "auto":
             method = "sorted" if (n_win >= (1 << 24) and text_bytes < (1 << 36)) else "table"
+        self.last_substr_candidates = None
         if method == "sorted":
             slack = 2048 * 28 * torch.cuda.get_device_properties(self.device).multi_processor_count + 14336
             per_win = 2 * 8 + 2                                                  # two entry arrays + the u16 side array
-            n_parts = max(1, -(-int(1.06 * n_win * per_win + slack * per_win) // max(1, table_bytes)),
-                          -(-n_win // (1 << 33)))      # and at most 2^33 windows per pass (2^22 leaves of ~2000: 4-5 LDS rounds per leaf)
-            cap = int(1.06 * n_win / n_parts) + slack + (n_win // n_parts // 16 if n_parts > 1 else 0)   # key partitions are only nearly equal
+            ws = self.empty(self.SUBSTR_WS_WORDS, torch.int64)
+            cand = None
+            n_sort = n_win                              # windows the passes have to sort
+            if window >= 50 and self.substr_filter:
+                # candidate filter (mdd_substr_candidates): only windows whose selected 32-byte k-gram occurs twice in the
+                # corpus can repeat; one anchor per ~10 windows goes through the same sort first.  A quarter of the windows
+                # is ample room for them (beyond it the filter switches itself off: every position comes back flagged).
+                cap_a = max(n_win // 4, (text_bytes + 71) // 8) + slack
+                cap_a = min(cap_a, max(slack + (text_bytes + 71) // 8, table_bytes // per_win))
+                ent_a, ent_b = self.empty(cap_a, torch.int64), self.empty(cap_a, torch.int64)
+                d1 = self.empty(cap_a, torch.int16)
+                cand = self.empty(max(8, text_bytes), torch.uint8)
+                n_cand = torch.zeros(1, dtype=torch.int64, device=self.device)
+                _lib.check(self.L.mdd_substr_candidates(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(ent_a), _ptr(ent_b),
+                                                        cap_a, _ptr(d1), _ptr(ws), ws.numel(), _ptr(cand), _ptr(n_cand)),
+                           "mdd_substr_candidates")
+                n_sort = min(n_win, int(n_cand.item()))
+                self.last_substr_candidates = (n_sort, n_win)
+                del ent_a, ent_b, d1
+            n_parts = max(1, -(-int(1.06 * n_sort * per_win + slack * per_win) // max(1, table_bytes)),
+                          -(-n_sort // (1 << 33)))     # and at most 2^33 windows per pass (2^22 leaves of ~2000: 4-5 LDS rounds per leaf)
+            cap = int(1.06 * n_sort / n_parts) + slack + (n_sort // n_parts // 16 if n_parts > 1 else 0)   # key partitions are only nearly equal
             ent_a, ent_b = self.empty(cap, torch.int64), self.empty(cap, torch.int64)
             d1 = self.empty(cap, torch.int16)
-            ws = self.empty(self.SUBSTR_WS_WORDS, torch.int64)
             for part in range(n_parts):
                 _lib.check(self.L.mdd_substr_mark_sorted(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
-                                                         _ptr(ent_a), _ptr(ent_b), cap, _ptr(d1), _ptr(ws), ws.numel(), _ptr(dup)),
+                                                         _ptr(ent_a), _ptr(ent_b), cap, _ptr(d1), _ptr(ws), ws.numel(), _ptr(dup),
+                                                         _ptr(cand) if cand is not None else None),
                            "mdd_substr_mark_sorted")
             if os.environ.get("MDD_LEAF_PROF"):      # profiling builds (-DMDD_LEAF_PROF): cycles per leaf-kernel phase
                 torch.cuda.synchronize(self.device)
                 base = (2048 + 1) + 2048 + (2 ** 22 + 1) + 2 ** 22 + 1024 + 2 ** 21
                 self.last_leaf_prof = ws[base + 1: base + 6].tolist()
-            del ent_a, ent_b, d1, ws        # the workspace (most of the free HBM) goes back before the outputs are allocated
+            del ent_a, ent_b, d1, ws, cand  # the workspace (most of the free HBM) goes back before the outputs are allocated
         else:
             n_parts = max(1, -(-(16 * n_win) // max(1, table_bytes)))
             slots = 2 * n_win if n_parts == 1 else int(2.2 * n_win / n_parts) + 4096      # hash partitions are only nearly equal

@@ -285,12 +285,21 @@ def test_substr_sorted_method_heavy_repetition_and_parts(sorted_method):
     text, offs = corpus.generate_chunked(spec, engine.device)
     a = engine.substr_dedup(text, offs, 50, 20, method="sorted")
     assert engine.last_substr_parts == 1 and engine.last_substr_method == "sorted"
+    n_sort, n_win = engine.last_substr_candidates        # (windows left by the candidate filter, all windows)
     b = engine.substr_dedup(text, offs, 50, 20, method="table")
     n = int(a[1][-1].item())
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0][:n], b[0][:n]) and 0 < n < int(offs[-1].item())
-    n_win = int(torch.clamp(offs[1:] - offs[:-1] - 50, min=0).sum().item())
-    c = engine.substr_dedup(text, offs, 50, 20, method="sorted", table_bytes=int(18 * 1.06 * n_win / 3))
+    assert 0 < n_sort <= n_win == int(torch.clamp(offs[1:] - offs[:-1] - 50, min=0).sum().item())
+    c = engine.substr_dedup(text, offs, 50, 20, method="sorted", table_bytes=int(18 * 1.06 * n_sort / 3))
     assert engine.last_substr_parts >= 3
+    engine.substr_filter = False
+    try:
+        c2 = engine.substr_dedup(text, offs, 50, 20, method="sorted", table_bytes=int(18 * 1.06 * n_win / 3))
+    finally:
+        engine.substr_filter = True
+    assert engine.last_substr_parts >= 3
+    assert torch.equal(a[1], c2[1]) and torch.equal(a[2], c2[2]) and torch.equal(a[0][:n], c2[0][:n])
+    del c2
     assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]) and torch.equal(a[0][:n], c[0][:n])
     # leaves above 640 windows are grouped in several rounds over shares of the tag space; the knob lowers the limits so that
     # this corpus (48 windows per leaf on average) takes 4-5 rounds per leaf
@@ -333,3 +342,78 @@ def test_substr_sorted_method_big_leaves(sorted_method):
     b = engine.substr_dedup(text, offs, 50, 20, method="table")
     n = int(a[1][-1].item())
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0][:n], b[0][:n]) and 0 < n < int(offs[-1].item())
+
+
+def test_substr_candidate_filter_adversarial_vs_oracle(sorted_method):
+    """mdd_substr_candidates in front of the sorted method (window >= 50): repeats planted at every dword alignment, at the
+    first / last hashable window of a document, across the 200-byte steps of the anchor kernel, across segment borders,
+    inside multi-byte text, between a pure-ASCII and a non-ASCII document, runs of one character (every position an
+    anchor), periodic text -- against the oracle, with the filter on and off"""
+    engine = sorted_method
+    rng = np.random.Generator(np.random.PCG64(2024))
+    alpha = [chr(c) for c in range(0x61, 0x7B)] + [" "] * 4
+
+    def rnd(n, extra=()):
+        return "".join(rng.choice(alpha + list(extra), n))
+
+    for rep in range(8):
+        window = [50, 50, 64, 50, 128, 50, 50, 57][rep]
+        seg = [0, 256, 0, 512, 0, 0, 256, 0][rep]
+        passages = [rnd(int(rng.integers(window - 3, window + 40))) for _ in range(6)]
+        passages += [rnd(window + 20, ("é", "数", "😀")) for _ in range(3)]
+        passages += ["-" * (window + 30), "ab" * (window // 2 + 20), "xyz" * (window // 3 + 25)]
+        docs = []
+        for i in range(70):
+            parts = []
+            for _ in range(int(rng.integers(1, 5))):
+                parts.append(rnd(int(rng.integers(0, 330)), ("é",) if i % 3 == 0 else ()))      # filler of every length: all alignments, all step phases
+                parts.append(passages[int(rng.integers(0, len(passages)))])
+            if i % 5 == 0:
+                parts.append(rnd(int(rng.integers(0, 3))))
+            docs.append("".join(parts))
+        p0 = passages[0]
+        docs += [p0, p0 + "x", "y" + p0, p0[: window] + "z", p0[: window], p0[1:] + "q", "", "short"]
+        docs += [rnd(3000) + p0 + rnd(2500) + passages[1] + rnd(700)]                             # long document: many steps, segments
+        rows = [(d, i) for i, d in enumerate(docs)]
+        exp = RX.exact_substr_dedup(rows, window, 20)
+        engine.set_segment_bytes(seg)
+        try:
+            for flt in (True, False):
+                engine.substr_filter = flt
+                got = exact.exact_substr_dedup(engine, rows, window, 20)
+                assert got == exp, (rep, window, seg, flt)
+                assert engine.last_substr_method == "sorted" and (engine.last_substr_candidates is not None) == flt
+        finally:
+            engine.set_segment_bytes(0)
+            engine.substr_filter = True
+
+
+def test_substr_candidate_filter_at_scale(sorted_method):
+    """200 k synthetic documents (15 % near-copies): the filter keeps under half of the windows, the survivors are those of
+    the unfiltered sorted method and of the table method; so are they when the anchors do not fit their array (the filter
+    then flags every position)"""
+    import torch
+    from map_neo_amd import corpus
+    engine = sorted_method
+    spec = corpus.CorpusSpec(200_000, 2048, lang="en", seed=9)
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    a = engine.substr_dedup(text, offs, 50, 20, method="sorted")
+    n_sort, n_win = engine.last_substr_candidates
+    assert 0 < n_sort < 0.5 * n_win
+    n = int(a[1][-1].item())
+    engine.substr_filter = False
+    try:
+        b = engine.substr_dedup(text, offs, 50, 20, method="sorted")
+        assert engine.last_substr_candidates is None
+    finally:
+        engine.substr_filter = True
+    c = engine.substr_dedup(text, offs, 50, 20, method="table")
+    for r in (b, c):
+        assert torch.equal(a[1], r[1]) and torch.equal(a[2], r[2]) and torch.equal(a[0][:n], r[0][:n]) and 0 < n < int(offs[-1].item())
+    # mixed EN / ZH documents: windows of 50 code points are 50 .. 150 bytes long
+    spec = corpus.CorpusSpec(60_000, 2048, lang="mixed", seed=10)
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    a = engine.substr_dedup(text, offs, 50, 20, method="sorted")
+    c = engine.substr_dedup(text, offs, 50, 20, method="table")
+    n = int(a[1][-1].item())
+    assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]) and torch.equal(a[0][:n], c[0][:n]) and 0 < n < int(offs[-1].item())
