@@ -333,7 +333,8 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          counted and reported by mdd_substr_check: redo with more parts, or use `mark`.
  *          cand (round 3; NULL = every window takes part): u8[text_bytes] from mdd_substr_candidates -- windows whose
  *          flag is 0 are skipped.  The marks are the same with and without it; ent_cap then only has to hold the
- *          candidate windows of the pass.
+ *          candidate windows of the pass; dup is NOT cleared by part 0 then (mdd_substr_candidates has cleared it and,
+ *          for window = 50, already holds marks).
  *   candidates: the filter in front of mark_sorted (same reference lines: it decides nothing, it only proves windows
  *          unique).  A window that occurs twice holds the same 32-byte k-grams at the same offsets in both copies, so
  *          it can only take part in a group when the k-gram its bytes select -- the one with the smallest hash among
@@ -343,7 +344,12 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          off, they do not fail the call), and cand[p] = 1 for every byte position p with a repeated anchor in
  *          [p, p + 18].  *n_cand (DEVICE) = number of flagged positions, an upper bound of the windows mark_sorted
  *          will sort.  Asynchronous.  50 <= window <= 128 (a window of w code points has >= w bytes; below 50 bytes
- *          the selection does not fit: call mark_sorted with cand = NULL); cand 8-byte aligned.  On C2 (1 M documents,
+ *          the selection does not fit: call mark_sorted with cand = NULL); cand 8-byte aligned.
+ *          dup: u8[text_bytes], cleared here.  For window = 50 the repeated anchors are settled on the spot: the 68 bytes
+ *          around an anchor are compared with those around the earlier anchors of its key, which decides all 19 windows
+ *          that can select it; their marks go straight into dup and only what that comparison cannot vouch for (bytes
+ *          >= 0x80 in the region, keys with more than 32 anchors, leaves of more than 768 anchors) is flagged in cand for
+ *          mark_sorted.  *n_cand == 0 then means dup is final.  On C2 (1 M documents,
  *          15 % near-copies) 28 % of the windows remain and the stage takes 61 instead of 80 ms. */
 #define MDD_SUBSTR_SORTED_WS_WORDS 11672587ull
 int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
@@ -351,7 +357,7 @@ int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
                            uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup, const uint8_t* cand);
 int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                           int window, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap, uint16_t* d1_ws, uint64_t* ws,
-                          uint64_t ws_words, uint8_t* cand, uint64_t* n_cand);
+                          uint64_t ws_words, uint8_t* cand, uint64_t* n_cand, uint8_t* dup);
 /*   check: mark is asynchronous and cannot validate tab_size against the (device-side) number of windows.  A window
  *          that finds neither its content nor a free slot is counted on the device; mdd_substr_check synchronises
  *          the stream, stores that count in *n_overflow_host (HOST, may be NULL), clears it and returns

@@ -1107,6 +1107,355 @@ __global__ void __launch_bounds__(64) anchor_leaf_kernel(const uint64_t* __restr
     }
 }
 
+// ---- resolving repeated anchors on the spot (window == 50) ----------------------------------------------------------
+// vmap[p] = 1 when a window of `window` code points that the stage hashes starts at byte p: p is a code-point start of its
+// document and more than `window` code points start at or after it (SUB:38 range(len(text) - duplicate_len)).  One wave per
+// document: count the code points (and see whether there is a byte >= 0x80 at all), then write -- pure-ASCII documents are
+// not read a second time.  Dword stores inside the document, byte stores where a dword is shared with a neighbour.
+__global__ void __launch_bounds__(256) vmap_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes, const uint64_t* __restrict__ offs,
+                                                   uint64_t n, uint32_t window, uint8_t* __restrict__ vmap) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
+    uint32_t* __restrict__ vw = reinterpret_cast<uint32_t*>(vmap);
+    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
+        uint64_t b, e;
+        doc_range(offs, d, text_bytes, b, e);
+        if (b >= e) continue;
+        const uint64_t w0 = b >> 2, w1 = (e + 3) >> 2;
+        auto inside = [&](uint64_t i) -> uint32_t {  // bytes of dword i inside [b, e), as bit 7 of each byte
+            const uint64_t p = i << 2;
+            uint32_t in = 0x80808080u;
+            if (p < b || p + 4 > e) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (p + k < b || p + k >= e) in &= ~(0x80u << (8 * k));
+            }
+            return in;
+        };
+        auto put = [&](uint64_t i, uint32_t in, uint32_t v) {  // v: 0 / 1 per byte
+            if (in == 0x80808080u && (i + 1) * 4 <= text_bytes) {
+                vw[i] = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((in & (0x80u << (8 * k))) && i * 4 + k < text_bytes) vmap[i * 4 + k] = (uint8_t)(v >> (8 * k));
+            }
+        };
+        uint32_t cnt = 0, hi_bits = 0;
+        for (uint64_t wi = w0; wi < w1; wi += 256) {
+            uint32_t ww[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                ww[j] = i < w1 ? tw[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = wi + 64 * j + lane;
+                if (i < w1) {
+                    const uint32_t in = inside(i), w = ww[j];
+                    cnt += (uint32_t)__builtin_popcount(in & ~(w & ~(w << 1)));  // not a continuation byte 10xxxxxx
+                    hi_bits |= w & in;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+        const bool ascii = __ballot((hi_bits & 0x80808080u) != 0u) == 0ull;
+        const uint64_t ncp = cnt;  // code points of the document; window c (0-based code point index) is hashed iff c + window < ncp
+        if (ascii) {
+            const uint64_t nv = ncp > window ? ncp - window : 0;  // valid starts: bytes b .. b + nv - 1
+            for (uint64_t i = w0 + lane; i < w1; i += 64) {
+                const uint32_t in = inside(i);
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (i * 4 + k >= b && i * 4 + k < b + nv) v |= 1u << (8 * k);
+                put(i, in, v);
+            }
+        } else {
+            uint64_t done = 0;  // code points that start before this step
+            for (uint64_t wi = w0; wi < w1; wi += 64) {
+                const uint64_t i = wi + lane;
+                const uint32_t in = i < w1 ? inside(i) : 0u;
+                const uint32_t w = i < w1 ? tw[i] : 0u;
+                const uint32_t S = in & ~(w & ~(w << 1));  // code-point starts
+                const uint32_t c = (uint32_t)__builtin_popcount(S);
+                const uint64_t B0 = __ballot(c & 1u), B1 = __ballot(c & 2u), B2 = __ballot(c & 4u);
+                uint64_t idx = done + __builtin_popcountll(B0 & lt) + 2 * __builtin_popcountll(B1 & lt) + 4 * __builtin_popcountll(B2 & lt);
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (S & (0x80u << (8 * k))) {
+                        if (idx + window < ncp) v |= 1u << (8 * k);
+                        idx++;
+                    }
+                if (i < w1) put(i, in, v);
+                done += __builtin_popcountll(B0) + 2 * __builtin_popcountll(B1) + 4 * __builtin_popcountll(B2);
+            }
+        }
+    }
+}
+
+// One wave per leaf of anchors, window = 50.  Anchors with equal keys form a group (an LDS table slot keeps the group's
+// LOWEST anchor, a chain through the leaf's entries lists its members).  For a member a and an earlier member b the 68 bytes
+// [a - 18, a + 50) -- every window that has the k-gram at a among its first 19 positions -- are compared with the bytes
+// around b: with l matching bytes before the k-gram and r behind it, the windows a - 18 + u, u in [18 - l, r], equal the
+// windows b - 18 + u; those that are hashed windows on both sides (vmap) are repeats: dup = 1.  A member compares with the
+// group's lowest anchor first (in a cluster of near-copies that is the original: one comparison explains all 19 windows) and
+// walks the chain only while a hashed window of its own is still unexplained.  Every identical earlier window has its own
+// selected k-gram in the same group, so after the walk a window is marked iff the stage marks it.  What this pass cannot
+// vouch for -- a byte >= 0x80 in the region (windows are then longer than 50 bytes), a group above RS_GROUP members, a leaf
+// too big for the table, an anchor in the first 20 bytes of the text -- is flagged, WITH ITS WHOLE GROUP, for the window
+// sort (mdd_substr_mark_sorted): both copies of a repeated window are then sorted, as the filter alone would have it.
+constexpr uint32_t RS_MAX = 768;     // anchors per leaf that go through the table (1024 slots)
+constexpr uint32_t RS_CH = RS_MAX / 64;
+constexpr uint32_t RS_GROUP = 32;    // chain steps a member takes before its group is handed to the window sort
+constexpr uint32_t RS_LIST = 128;    // work list: members with an earlier anchor in their group
+constexpr uint32_t RS_NIL = 0xFFFFu;
+struct ResolveLds {
+    unsigned long long tab[LEAF_SLOTS];  // [d2 | tag | position] of the group's lowest anchor; all-ones = empty
+    uint32_t head[LEAF_SLOTS];           // index (inside the leaf) of the group's most recently chained member
+    uint16_t next[RS_MAX];
+    uint32_t fb[LEAF_SLOTS / 32];        // groups handed to the window sort
+    unsigned long long lval[RS_LIST];
+    uint16_t lslot[RS_LIST];
+};
+constexpr unsigned RS_WAVES_PER_CU = 10;
+static_assert(RS_WAVES_PER_CU * sizeof(ResolveLds) <= 160 * 1024, "the resolve kernel's workgroups must all be resident");
+struct ResolveArgs {
+    const uint64_t* ent;
+    const uint64_t* off2;
+    uint32_t n_leaves;
+    const uint8_t* text;
+    uint64_t text_bytes;
+    const uint8_t* vmap;
+    uint8_t* dup;
+    uint8_t* flag;
+    uint32_t max_group;  // RS_GROUP (a tuning knob lowers / raises it: MDD_SUBSTR_GROUP)
+};
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// bit u of the result: byte u of the 19 bytes at p is non-zero (vmap bytes are 0 / 1)
+__device__ __forceinline__ uint32_t vmask19(const uint8_t* vmap, uint64_t p) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(vmap) + (p >> 2);
+    const uint32_t sh = (uint32_t)p & 3u;
+    uint32_t r[6];
+    const u32x4_a4 v0 = *reinterpret_cast<const u32x4_a4*>(q);
+    const u32x2_a4 v1 = *reinterpret_cast<const u32x2_a4*>(q + 4);
+    r[0] = v0.x, r[1] = v0.y, r[2] = v0.z, r[3] = v0.w, r[4] = v1.x, r[5] = v1.y;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t w = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & 0x01010101u;
+        m |= ((w * 0x01020408u) >> 24) << (4 * k);  // bytes 0..3 -> bits 0..3
+    }
+    return m & 0x7FFFFu;
+}
+
+// region of an anchor at a: the 72 bytes from a - 20 as 18 dwords
+__device__ __forceinline__ void load_region(const uint8_t* text, uint64_t a, uint32_t (&R)[18]) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(text) + ((a - 20) >> 2);
+    const uint32_t sh = (uint32_t)(a - 20) & 3u;
+    uint32_t r[20];
+#pragma unroll
+    for (int k = 0; k < 20; k += 4) {
+        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(q + k);
+        r[k] = v.x, r[k + 1] = v.y, r[k + 2] = v.z, r[k + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 18; k++) R[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh);
+}
+// windows (bit u = the window at a - 18 + u) whose 50 bytes equal the window at the same offset from b
+__device__ __forceinline__ uint32_t region_match(const uint32_t (&Ra)[18], const uint32_t (&Rb)[18]) {
+    uint32_t x[18], kg = 0;
+#pragma unroll
+    for (int k = 0; k < 18; k++) x[k] = Ra[k] ^ Rb[k];
+#pragma unroll
+    for (int k = 5; k < 13; k++) kg |= x[k];  // the k-gram itself: region bytes 20 .. 51
+    if (kg) return 0u;
+    uint32_t l = 0, r = 0;
+    bool open = true;
+#pragma unroll
+    for (int k = 4; k >= 0; k--)  // bytes 19 down to 0
+        if (open) {
+            if (x[k] == 0u) l += 4;
+            else l += (uint32_t)__builtin_clz(x[k]) >> 3, open = false;
+        }
+    open = true;
+#pragma unroll
+    for (int k = 13; k < 18; k++)  // bytes 52 up to 71
+        if (open) {
+            if (x[k] == 0u) r += 4;
+            else r += (uint32_t)__builtin_ctz(x[k]) >> 3, open = false;
+        }
+    l = l < 18u ? l : 18u;
+    r = r < 18u ? r : 18u;
+    if (18u - l > r) return 0u;
+    return (0x7FFFFu >> (18u - r)) & (0x7FFFFu << (18u - l)) & 0x7FFFFu;  // bits 18 - l .. r
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) anchor_resolve_kernel(ResolveArgs A) {
+    __shared__ ResolveLds L;
+    const uint32_t lane = lane_id();
+    auto find_slot = [&](unsigned long long val) -> uint32_t {  // the slot of val's group (val has been inserted)
+        uint32_t slot = leaf_home(val);
+        for (uint32_t probe = 0; probe < LEAF_SLOTS && (L.tab[slot] >> POS_BITS) != (val >> POS_BITS); probe++) slot = (slot + 1) & (LEAF_SLOTS - 1);
+        return slot;
+    };
+    for (uint32_t leaf = blockIdx.x; leaf < A.n_leaves; leaf += gridDim.x) {
+        const uint64_t lo = A.off2[leaf], hi = A.off2[leaf + 1];
+        if (hi - lo < 2) continue;
+        if (hi - lo > RS_MAX) {  // cannot happen to unrelated keys (a leaf holds ~400): heavy repetition, the window sort's business
+            for (uint64_t i = lo + lane; i < hi; i += 64) {
+                const uint64_t pos = A.ent[i] & POS_M;
+                if (pos < A.text_bytes) A.flag[pos] = 1;
+            }
+            continue;
+        }
+        unsigned long long e[RS_CH];
+#pragma unroll
+        for (uint32_t k = 0; k < RS_CH; k++) {
+            const uint64_t i = lo + (uint64_t)k * 64 + lane;
+            e[k] = i < hi ? A.ent[i] : ENT_INVALID;
+        }
+#pragma unroll
+        for (int i = 0; i < LEAF_SLOTS / 64; i++) {
+            L.tab[i * 64 + lane] = ENT_INVALID;
+            L.head[i * 64 + lane] = RS_NIL;
+        }
+        if (lane < LEAF_SLOTS / 32) L.fb[lane] = 0;
+        lds_sync();
+        // ---- 1. groups: the slot keeps the lowest anchor of its key, the chain every member
+#pragma unroll 1
+        for (uint32_t k = 0; k < RS_CH; k++) {
+            const unsigned long long val = e[0];
+#pragma unroll
+            for (uint32_t j = 0; j + 1 < RS_CH; j++) e[j] = e[j + 1];
+            e[RS_CH - 1] = ENT_INVALID;
+            if (val == ENT_INVALID) continue;
+            uint32_t slot = leaf_home(val);
+            for (uint32_t probe = 0; probe < LEAF_SLOTS; probe++) {
+                const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
+                if (cur == ENT_INVALID) break;
+                if ((cur >> POS_BITS) == (val >> POS_BITS)) {
+                    if (val < cur) atomicMin(&L.tab[slot], val);
+                    break;
+                }
+                slot = (slot + 1) & (LEAF_SLOTS - 1);
+            }
+            const uint32_t idx = k * 64 + lane;
+            L.next[idx] = (uint16_t)atomicExch(&L.head[slot], idx);
+        }
+        lds_sync();
+        // ---- 2. members with an earlier anchor in their group, 64 at a time with every lane busy
+        uint32_t n_list = 0;
+        auto drain = [&](bool all) {
+            lds_sync();
+            uint32_t base = 0;
+            for (; all ? base < n_list : base + 64 <= n_list; base += 64) {
+                if (base + lane < n_list) {
+                    const unsigned long long val = L.lval[base + lane];
+                    const uint32_t slot = L.lslot[base + lane];
+                    const uint64_t a = val & POS_M;
+                    bool vouch = a >= 20 && a + 52 <= A.text_bytes + MDD_TEXT_PAD;
+                    uint32_t left = 0;  // hashed windows of this anchor that no earlier member explains yet
+                    if (vouch) {
+                        uint32_t Ra[18];
+                        load_region(A.text, a, Ra);
+                        const uint32_t va = vmask19(A.vmap, a - 18);
+                        uint32_t hi_or = 0;
+#pragma unroll
+                        for (int k = 0; k < 18; k++) hi_or |= Ra[k];
+                        vouch = (hi_or & 0x80808080u) == 0u;
+                        left = va;
+                        uint32_t marks = 0;
+                        if (vouch && left) {
+                            const uint64_t b = L.tab[slot] & POS_M;  // the group's lowest anchor first
+                            if (b < a && b >= 20) {
+                                uint32_t Rb[18];
+                                load_region(A.text, b, Rb);
+                                const uint32_t m = region_match(Ra, Rb) & vmask19(A.vmap, b - 18) & va;
+                                marks |= m;
+                                left &= ~m;
+                            } else if (b < 20) {
+                                vouch = false;
+                            }
+                            uint32_t steps = 0;
+                            for (uint32_t i = L.head[slot]; vouch && left && i != RS_NIL; i = L.next[i]) {
+                                if (++steps > A.max_group) {
+                                    vouch = false;
+                                    break;
+                                }
+                                const uint64_t b2 = A.ent[lo + i] & POS_M;
+                                if (b2 >= a || b2 == b) continue;
+                                if (b2 < 20) {
+                                    vouch = false;
+                                    break;
+                                }
+                                uint32_t Rb[18];
+                                load_region(A.text, b2, Rb);
+                                const uint32_t m = region_match(Ra, Rb) & vmask19(A.vmap, b2 - 18) & va;
+                                marks |= m;
+                                left &= ~m;
+                            }
+                        }
+                        // verified repeats are repeats whatever becomes of the group
+#pragma unroll 1
+                        for (uint32_t u = 0; u < 19; u++)
+                            if ((marks >> u) & 1u) A.dup[a - 18 + u] = 1;
+                    }
+                    if (!vouch) atomicOr(&L.fb[slot >> 5], 1u << (slot & 31u));
+                }
+            }
+            const uint32_t rest = base < n_list ? n_list - base : 0u;
+            if (rest && base) {
+                unsigned long long v = 0;
+                uint16_t sl = 0;
+                if (lane < rest) v = L.lval[base + lane], sl = L.lslot[base + lane];
+                lds_sync();
+                if (lane < rest) L.lval[lane] = v, L.lslot[lane] = sl;
+            }
+            lds_sync();
+            n_list = rest;
+        };
+        for (uint64_t c0 = lo; c0 < hi; c0 += 64) {
+            const uint64_t i = c0 + lane;
+            bool work = false;
+            unsigned long long val = ENT_INVALID;
+            uint32_t slot = 0;
+            if (i < hi) {
+                val = A.ent[i];  // (second read: from the L2)
+                slot = find_slot(val);
+                work = L.tab[slot] != val;  // not the group's lowest anchor (a lone anchor is its group's lowest)
+            }
+            const uint64_t wb = __ballot(work);
+            if (work) {
+                const uint32_t at = n_list + below(wb);
+                L.lval[at] = val;
+                L.lslot[at] = (uint16_t)slot;
+            }
+            n_list += (uint32_t)__popcll(wb);
+            if (n_list > RS_LIST - 64) drain(false);
+        }
+        drain(true);
+        // ---- 3. groups this pass cannot vouch for: every member is flagged for the window sort
+        bool any_fb = false;
+        if (lane < LEAF_SLOTS / 32) any_fb = L.fb[lane] != 0u;
+        if (__ballot(any_fb)) {
+            for (uint64_t i = lo + lane; i < hi; i += 64) {
+                const unsigned long long val = A.ent[i];
+                const uint32_t slot = find_slot(val);
+                const uint64_t pos = val & POS_M;
+                if (((L.fb[slot >> 5] >> (slot & 31u)) & 1u) && pos < A.text_bytes) A.flag[pos] = 1;
+            }
+        }
+        lds_sync();
+    }
+}
+
 // cand[p] = 1 when an anchor in [p, p + 18] is flagged (window p selects one of these positions; flagging all of them is
 // a superset).  8 positions per thread; flag has 32 readable zero bytes past text_bytes.  *overflow != 0 (anchors without
 // room in the entry array): every position is a candidate.  *n_cand += candidate positions.
@@ -1235,7 +1584,7 @@ int plan_segments(mdd_ctx* ctx, const char* who, const uint64_t* offsets, uint64
 
 extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                                      int window, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap, uint16_t* d1_ws, uint64_t* ws,
-                                     uint64_t ws_words, uint8_t* cand, uint64_t* n_cand) {
+                                     uint64_t ws_words, uint8_t* cand, uint64_t* n_cand, uint8_t* dup) {
     REQUIRE(ctx, "mdd_substr_candidates: ctx is NULL");
     REQUIRE(window >= (int)AN_MINWIN && window <= 128, "mdd_substr_candidates: window=%d outside [%u,128] (smaller windows: no filter, pass cand = NULL to mdd_substr_mark_sorted)",
             window, AN_MINWIN);
@@ -1245,7 +1594,7 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemsetAsync(n_cand, 0, sizeof(uint64_t), st));
     if (n_docs == 0 || text_bytes == 0) return MDD_OK;
-    REQUIRE(text && offsets && ent_a && ent_b && d1_ws && ws && cand, "mdd_substr_candidates: NULL buffer");
+    REQUIRE(text && offsets && ent_a && ent_b && d1_ws && ws && cand && dup, "mdd_substr_candidates: NULL buffer");
     REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_candidates: text must be 4-byte aligned");
     REQUIRE(ws_words >= SortWs::WORDS, "mdd_substr_candidates: workspace of %llu u64 words needed (MDD_SUBSTR_SORTED_WS_WORDS)",
             (unsigned long long)SortWs::WORDS);
@@ -1262,6 +1611,16 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     {
         int rc = W.clear(st);
         if (rc) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));
+    const bool resolve = window == (int)AN_MINWIN;  // repeated anchors are settled in their leaves (anchor_resolve_kernel)
+    if (resolve) {
+        // cand holds the map of hashed window starts until smear_kernel overwrites it (bytes outside every document: 0)
+        HIP_TRY(hipMemsetAsync(cand, 0, text_bytes, st));
+        uint64_t blocks = (n_docs + 3) / 4, cap = (uint64_t)ctx->cus * 64;
+        hipLaunchKernelGGL(vmap_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, st, text, text_bytes, offsets, n_docs,
+                           (uint32_t)window, cand);
+        HIP_TRY(hipGetLastError());
     }
     AnchorArgs E{};
     E.text = text;
@@ -1293,8 +1652,27 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     }
     uint8_t* flag = reinterpret_cast<uint8_t*>(ent_b);
     HIP_TRY(hipMemsetAsync(flag, 0, text_bytes + 64, st));
-    hipLaunchKernelGGL(anchor_leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, ent_a, W.off2, 256u * (uint32_t)BINS2, flag,
-                       text_bytes);
+    const uint32_t n_leaves_a = 256u * (uint32_t)BINS2;  // anchors carry an 8-bit level-1 digit
+    if (resolve && !getenv("MDD_SUBSTR_NO_RESOLVE")) {     // (the knob: A/B runs and tests of the filter-only path)
+        ResolveArgs R{};
+        R.ent = ent_a;
+        R.off2 = W.off2;
+        R.n_leaves = n_leaves_a;
+        R.text = text;
+        R.text_bytes = text_bytes;
+        R.vmap = cand;
+        R.dup = dup;
+        R.flag = flag;
+        R.max_group = RS_GROUP;
+        if (const char* knob = getenv("MDD_SUBSTR_GROUP")) {
+            const int g = atoi(knob);
+            if (g >= 1 && g <= (int)RS_MAX) R.max_group = (uint32_t)g;
+        }
+        hipLaunchKernelGGL(anchor_resolve_kernel, dim3((unsigned)ctx->cus * RS_WAVES_PER_CU), dim3(64), 0, st, R);
+    } else {
+        hipLaunchKernelGGL(anchor_leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, ent_a, W.off2, n_leaves_a, flag,
+                           text_bytes);
+    }
     const uint64_t smear_blocks = (text_bytes + 2047) / 2048, smear_cap = (uint64_t)ctx->cus * 16;
     hipLaunchKernelGGL(smear_kernel, dim3((unsigned)(smear_blocks < smear_cap ? smear_blocks : smear_cap)), dim3(256), 0, st, flag, text_bytes, cand,
                        reinterpret_cast<unsigned long long*>(n_cand), W.counters + 7);
@@ -1330,7 +1708,7 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
         int rc = W.clear(st);
         if (rc) return rc;
     }
-    if (part == 0) HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));
+    if (part == 0 && !cand) HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));  // (with cand: mdd_substr_candidates cleared dup and may have marked repeats)
     // ---- emit
     EmitArgs E{};
     E.text = text;

@@ -51,7 +51,7 @@ SIGNATURES = {
     "mdd_para_compact_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _u64]),
     "mdd_substr_mark": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int, _int, _vp, _u64, _vp]),
     "mdd_substr_mark_sorted": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int, _int, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
-    "mdd_substr_candidates": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
+    "mdd_substr_candidates": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp]),
     "mdd_substr_check": (_int, [_vp, _vp]),
     "mdd_substr_count": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp]),
     "mdd_substr_write": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp, _vp, _u64]),

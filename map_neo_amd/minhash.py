@@ -449,20 +449,22 @@ class Engine:
                 cand = self.empty(max(8, text_bytes), torch.uint8)
                 n_cand = torch.zeros(1, dtype=torch.int64, device=self.device)
                 _lib.check(self.L.mdd_substr_candidates(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(ent_a), _ptr(ent_b),
-                                                        cap_a, _ptr(d1), _ptr(ws), ws.numel(), _ptr(cand), _ptr(n_cand)),
+                                                        cap_a, _ptr(d1), _ptr(ws), ws.numel(), _ptr(cand), _ptr(n_cand), _ptr(dup)),
                            "mdd_substr_candidates")
                 n_sort = min(n_win, int(n_cand.item()))
                 self.last_substr_candidates = (n_sort, n_win)
                 del ent_a, ent_b, d1
-            n_parts = max(1, -(-int(1.06 * n_sort * per_win + slack * per_win) // max(1, table_bytes)),
-                          -(-n_sort // (1 << 33)))     # and at most 2^33 windows per pass (2^22 leaves of ~2000: 4-5 LDS rounds per leaf)
-            cap = int(1.06 * n_sort / n_parts) + slack + (n_sort // n_parts // 16 if n_parts > 1 else 0)   # key partitions are only nearly equal
-            ent_a, ent_b = self.empty(cap, torch.int64), self.empty(cap, torch.int64)
-            d1 = self.empty(cap, torch.int16)
+            if cand is not None and n_sort == 0:        # every repeated anchor was settled in its leaf (window 50): dup is final
+                n_parts, ent_a, ent_b, d1, cap = 0, None, None, None, 0
+            else:
+                n_parts = max(1, -(-int(1.06 * n_sort * per_win + slack * per_win) // max(1, table_bytes)),
+                              -(-n_sort // (1 << 33)))     # and at most 2^33 windows per pass (2^22 leaves of ~2000: 4-5 LDS rounds per leaf)
+                cap = int(1.06 * n_sort / n_parts) + slack + (n_sort // n_parts // 16 if n_parts > 1 else 0)   # key partitions are only nearly equal
+                ent_a, ent_b = self.empty(cap, torch.int64), self.empty(cap, torch.int64)
+                d1 = self.empty(cap, torch.int16)
             for part in range(n_parts):
                 _lib.check(self.L.mdd_substr_mark_sorted(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, part, n_parts,
-                                                         _ptr(ent_a), _ptr(ent_b), cap, _ptr(d1), _ptr(ws), ws.numel(), _ptr(dup),
-                                                         _ptr(cand) if cand is not None else None),
+                                                         _ptr(ent_a), _ptr(ent_b), cap, _ptr(d1), _ptr(ws), ws.numel(), _ptr(dup), _ptr(cand)),
                            "mdd_substr_mark_sorted")
             if os.environ.get("MDD_LEAF_PROF"):      # profiling builds (-DMDD_LEAF_PROF): cycles per leaf-kernel phase
                 torch.cuda.synchronize(self.device)

@@ -417,3 +417,59 @@ def test_substr_candidate_filter_at_scale(sorted_method):
     c = engine.substr_dedup(text, offs, 50, 20, method="table")
     n = int(a[1][-1].item())
     assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]) and torch.equal(a[0][:n], c[0][:n]) and 0 < n < int(offs[-1].item())
+
+
+def test_substr_resolved_anchors_clusters_with_edits_vs_oracle(sorted_method):
+    """window 50: repeated anchors are settled in their leaves (anchor_resolve_kernel).  Clusters of 2 .. 45 near-copies of
+    a document with point edits, deletions and insertions at random places (every distance between an edit and an anchor;
+    groups above 32 members go to the window sort), copies cut so that a repeated passage ends exactly with its document
+    (the window that ends with the document is never hashed), begins it, or sits in a document shorter than 68 bytes;
+    with and without the resolve step, against the oracle"""
+    import os
+    engine = sorted_method
+    rng = np.random.Generator(np.random.PCG64(31))
+    alpha = [chr(c) for c in range(0x61, 0x7B)] + [" "] * 5
+    for rep in range(4):
+        docs = []
+        for cl in range(10):
+            base = "".join(rng.choice(alpha, int(rng.integers(60, 900))))
+            n_copy = int([1, 2, 3, 5, 9, 17, 33, 45, 2, 4][cl])
+            for c in range(n_copy):
+                t = list(base)
+                for _ in range(int(rng.integers(0, 6))):
+                    at = int(rng.integers(0, len(t)))
+                    kind = int(rng.integers(0, 4))
+                    if kind == 0:
+                        t[at] = "#" if rep % 2 else "é"                # an edit that is / is not ASCII
+                    elif kind == 1:
+                        del t[at]
+                    elif kind == 2:
+                        t.insert(at, "Q")
+                    else:
+                        t[at] = chr(int(rng.integers(0x61, 0x7B)))
+                t = "".join(t)
+                cut = int(rng.integers(0, 4))
+                if cut == 1:
+                    t = t[int(rng.integers(0, max(1, len(t) - 55))):]           # begins inside the base text
+                elif cut == 2:
+                    t = t[: int(rng.integers(50, len(t) + 1))]                  # ends inside it
+                elif cut == 3:
+                    a = int(rng.integers(0, max(1, len(t) - 60)))
+                    t = t[a: a + int(rng.integers(50, 70))]                     # a document of 50 .. 69 bytes
+                docs.append(t)
+        order = rng.permutation(len(docs))
+        rows = [(docs[int(i)], k) for k, i in enumerate(order)]
+        exp = RX.exact_substr_dedup(rows, 50, 20)
+        engine.set_segment_bytes([0, 256, 0, 512][rep])
+        try:
+            for knob in (None, "1"):
+                if knob:
+                    os.environ["MDD_SUBSTR_NO_RESOLVE"] = knob
+                try:
+                    got = exact.exact_substr_dedup(engine, rows, 50, 20)
+                finally:
+                    os.environ.pop("MDD_SUBSTR_NO_RESOLVE", None)
+                assert got == exp, (rep, knob)
+                assert engine.last_substr_candidates is not None
+        finally:
+            engine.set_segment_bytes(0)
