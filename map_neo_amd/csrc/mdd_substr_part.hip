@@ -102,6 +102,15 @@ __device__ __forceinline__ uint64_t entry_of(uint64_t key, uint64_t pos) {  // [
 }
 __device__ __forceinline__ uint32_t d2_of(uint64_t e) { return (uint32_t)(e >> (POS_BITS + TAG_BITS)); }
 
+// wave_sync() without its fences, which make the compiler wait for the global loads in flight (the next leaf's entries)
+// as well.  Between the lanes of ONE wave the LDS needs no fence -- DS instructions of a wave execute in issue order --
+// only the compiler must keep its hands off the order: a compiler-level memory barrier on both sides of the wave barrier.
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 struct EmitArgs {
     const uint8_t* text;
     uint64_t text_bytes;
@@ -121,15 +130,19 @@ struct EmitArgs {
     uint32_t part, n_parts;
     uint32_t batch_shift;  // a claim on the work counter takes (items left) >> batch_shift items, clamped to [1, 16]
     const uint8_t* cand;   // candidate flag per byte position (mdd_substr_candidates) or NULL: every window takes part
+    uint32_t max_batch;    // items per claim at most (16 without the filter; with it an item is cheap and batches of 64 keep the claims rare)
 };
 
 // persistent waves pulling documents (then queued segments of long documents) from one counter, four waves per workgroup
 // sharing the LDS histogram of d1; every wave leaves once the counter passes `total`
 constexpr int EMIT_WAVES = 4;
+constexpr int CPLANE_BLOCKS = 66;  // candidate-flag bit planes per wave: 66 blocks of 64 dwords = a 16 KiB segment + alignment
 __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
     __shared__ WaveLds lds_all[EMIT_WAVES];
     __shared__ unsigned int h1[BINS1];
+    __shared__ uint64_t cplane_all[EMIT_WAVES][CPLANE_BLOCKS * 4];
     WaveLds& lds = lds_all[threadIdx.x >> 6];
+    uint64_t* cplane = cplane_all[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
     for (int i = threadIdx.x; i < BINS1; i += 64 * EMIT_WAVES) h1[i] = 0;
     __syncthreads();
@@ -149,7 +162,7 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
     for (;; item++) {
         if (item >= batch_end) {  // `item` = end of this wave's previous batch: a lower bound of the counter
             const uint64_t want = (total > item ? total - item : 0) >> A.batch_shift;
-            const uint32_t n = want < 1u ? 1u : (want > 16u ? 16u : (uint32_t)want);
+            const uint32_t n = want < 1u ? 1u : (want > A.max_batch ? A.max_batch : (uint32_t)want);
             item = fetch(n);
             if (item >= total) break;
             batch_end = item + n < total ? item + n : total;
@@ -167,17 +180,141 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
         const bool split = len > A.seg_bytes;
         const uint32_t seg_beg = seg * A.seg_bytes;
         const uint32_t seg_end = (uint64_t)seg_beg + A.seg_bytes < len ? seg_beg + A.seg_bytes : len;
+        // With the candidate filter few windows are left and a round of 64 windows would wait a memory round trip for its 64
+        // flag bytes only to find none set.  So the item's flags are read ONCE (a dword per lane, all loads in flight) into
+        // bit planes in LDS: plane j of block k = ballot over the 64 dwords of block k of "byte j is set".  A window then
+        // finds its flag with one LDS read, and an item without any candidate is dropped before its text is touched.
+        uint64_t plane_dw0 = 0;   // dword index (of the flag array) of block 0
+        bool planes = false;
+        if (A.cand) {
+            const uint64_t p0 = beg + seg_beg, p1 = beg + seg_end;  // window starts of this item lie in [p0, p1)
+            if (p0 >= p1) continue;
+            const uint32_t* cw = reinterpret_cast<const uint32_t*>(A.cand);
+            const uint64_t full = A.text_bytes >> 2;  // dwords that lie inside the flag array
+            const uint64_t d0 = p0 >> 2, d1 = (p1 - 1) >> 2;
+            auto flags_of = [&](uint64_t i) -> uint32_t {
+                uint32_t v = 0;
+                if (i <= d1) {
+                    if (i < full) v = cw[i];
+                    else
+                        for (uint64_t q = i * 4; q < A.text_bytes; q++) v |= (uint32_t)A.cand[q] << (8 * (q - i * 4));
+                }
+                return v;
+            };
+            bool any = false;
+            if (d1 - d0 < (uint64_t)CPLANE_BLOCKS * 64) {
+                planes = true;
+                plane_dw0 = d0;
+                lds_sync();  // (the previous item's readers are done)
+                for (uint64_t blk = 0; d0 + blk * 64 <= d1; blk += 4) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = flags_of(d0 + (blk + u) * 64 + lane);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (d0 + (blk + u) * 64 > d1) break;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint64_t B = __ballot(((v[u] >> (8 * j)) & 0xFFu) != 0u);
+                            any = any || B != 0;
+                            if (lane == 0) cplane[(blk + u) * 4 + j] = B;
+                        }
+                    }
+                }
+                lds_sync();
+            } else {  // a segment beyond the planes (segments grow with texts beyond 16 GiB): flags straight from memory
+                uint32_t acc = 0;
+                for (uint64_t i = d0 + lane; i <= d1; i += 64) acc |= flags_of(i);
+                any = __ballot(acc != 0u) != 0ull;
+            }
+            if (!any) continue;
+        }
         TextView tv;
         tv.docw = tw + (beg >> 2);
         const uint32_t boff = (uint32_t)beg & 3u;
         const bool ascii = segment_is_ascii(tv, boff, len, seg_beg, seg_end, A.window, lane);
+        // the lanes with `on` append their window (content key, absolute position) to the entry array
+        auto put = [&](bool on, uint64_t key, uint64_t pos) {
+            const uint64_t bal = __ballot(on);
+            const uint32_t cnt = (uint32_t)__popcll(bal);
+            if (cnt == 0) return;
+            if (chunk_pos + cnt > chunk_end) {  // not enough room left: void the rest (< 64 entries) and take a new chunk
+                if (chunk_pos + lane < chunk_end && chunk_pos + lane < A.ent_cap) {
+                    A.ent[chunk_pos + lane] = ENT_INVALID;
+                    A.d1[chunk_pos + lane] = D1_INVALID;
+                }
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(A.n_ent, (unsigned long long)EMIT_CHUNK);
+                uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+                chunk_pos = ((uint64_t)hi << 32) | lo;
+                chunk_end = chunk_pos + EMIT_CHUNK;
+            }
+            if (on) {
+                uint64_t o = chunk_pos + below(bal);
+                if (o < A.ent_cap) {
+                    A.ent[o] = entry_of(key, pos);
+                    A.d1[o] = (uint16_t)d1_of(key);
+                    atomicAdd(&h1[d1_of(key)], 1u);
+                } else if (below(bal) == 0) {
+                    atomicAdd(A.overflow, 1ull);  // entry array too small (caller's contract): reported by mdd_substr_check
+                }
+            }
+            chunk_pos += cnt;
+        };
+        if (planes && ascii) {
+            // Pure-ASCII item under the filter: every byte offset is a window start, so the candidates are the set bits of
+            // the planes.  They are queued (the boundary ring is idle on this path) and hashed 64 at a time with every lane
+            // busy, instead of walking all rounds of 64 windows to find most of them empty.
+            if (len <= A.window) continue;
+            const uint32_t sb_end = seg_end < len - A.window ? seg_end : len - A.window;  // SUB:38: sb + window < len
+            uint32_t q_head = 0, q_tail = 0;
+            auto hash_queued = [&](uint32_t n) {
+                lds_sync();
+                const bool on0 = lane < n;
+                const uint32_t sb = lds.ringS[(q_head + (on0 ? lane : 0u)) & (RING - 1)];
+                bool on = on0;
+                uint64_t key = 0;
+                if (on) {
+                    key = A.window == 50u ? wkey_fixed<50>(tv, boff + sb) : wkey(tv, boff + sb, A.window);
+                    if (A.n_parts > 1 && (uint32_t)((key & 0x3FFFu) % A.n_parts) != A.part) on = false;
+                }
+                put(on, key, beg + sb);
+                q_head += n;
+                lds_sync();
+            };
+            const uint64_t d1 = (beg + seg_end - 1) >> 2;
+            for (uint64_t blk = 0; plane_dw0 + blk * 64 <= d1; blk++) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint64_t B = cplane[blk * 4 + j];
+                    if (B == 0) continue;
+                    const uint64_t q = (plane_dw0 + blk * 64 + lane) * 4 + j;  // absolute position of this lane's bit
+                    const bool sel = ((B >> lane) & 1ull) && q >= beg + seg_beg && q < beg + sb_end;
+                    const uint64_t sbal = __ballot(sel);
+                    if (sbal == 0) continue;
+                    if (sel) lds.ringS[(q_tail + below(sbal)) & (RING - 1)] = (uint32_t)(q - beg);
+                    q_tail += (uint32_t)__popcll(sbal);
+                    if (q_tail - q_head >= 64u) hash_queued(64u);
+                }
+            }
+            if (q_tail != q_head) hash_queued(q_tail - q_head);
+            continue;
+        }
         for_each_round(lds, A.text, beg, len, tv, boff, MDD_UNIT_CHAR, A.window, ascii, split, seg_beg, seg_end, lane,
                        [&](uint32_t s, uint32_t L, uint32_t nvalid, uint32_t) {
                            const uint32_t sb = s - boff;
                            // SUB:38 range(len(text) - duplicate_len): the window that ends with the document is never hashed
                            bool on = lane < nvalid && sb + L < len;
                            // candidate filter: a window whose selected k-gram occurs once in the corpus occurs once itself
-                           if (A.cand && on) on = A.cand[beg + sb] != 0;
+                           if (A.cand && on) {
+                               const uint64_t q = beg + sb;
+                               if (planes) {
+                                   const uint64_t dwi = (q >> 2) - plane_dw0;
+                                   on = (cplane[(dwi >> 6) * 4 + (q & 3u)] >> (dwi & 63u)) & 1ull;
+                               } else {
+                                   on = A.cand[q] != 0;
+                               }
+                           }
                            uint64_t key = 0;
                            if (on) {
                                // (selecting the pass from a cheap hash of the window's first bytes BEFORE the key was tried:
@@ -187,31 +324,7 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                                key = ascii ? (A.window == 50u ? wkey_fixed<50>(tv, s) : wkey(tv, s, A.window)) : wkey(tv, s, L);
                                if (A.n_parts > 1 && (uint32_t)((key & 0x3FFFu) % A.n_parts) != A.part) on = false;
                            }
-                           const uint64_t bal = __ballot(on);
-                           const uint32_t cnt = (uint32_t)__popcll(bal);
-                           if (cnt == 0) return;
-                           if (chunk_pos + cnt > chunk_end) {  // not enough room left: void the rest (< 64 entries) and take a new chunk
-                               if (chunk_pos + lane < chunk_end && chunk_pos + lane < A.ent_cap) {
-                                   A.ent[chunk_pos + lane] = ENT_INVALID;
-                                   A.d1[chunk_pos + lane] = D1_INVALID;
-                               }
-                               unsigned long long v = 0;
-                               if (lane == 0) v = atomicAdd(A.n_ent, (unsigned long long)EMIT_CHUNK);
-                               uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
-                               chunk_pos = ((uint64_t)hi << 32) | lo;
-                               chunk_end = chunk_pos + EMIT_CHUNK;
-                           }
-                           if (on) {
-                               uint64_t o = chunk_pos + below(bal);
-                               if (o < A.ent_cap) {
-                                   A.ent[o] = entry_of(key, beg + sb);
-                                   A.d1[o] = (uint16_t)d1_of(key);
-                                   atomicAdd(&h1[d1_of(key)], 1u);
-                               } else if (below(bal) == 0) {
-                                   atomicAdd(A.overflow, 1ull);  // entry array too small (caller's contract): reported by mdd_substr_check
-                               }
-                           }
-                           chunk_pos += cnt;
+                           put(on, key, beg + sb);
                        });
     }
     for (uint64_t i = chunk_pos + lane; i < chunk_end && i < A.ent_cap; i += 64) {  // void what is left of the last chunk
@@ -524,7 +637,17 @@ struct LeafArgs {
     unsigned int* big_list;    // [BIG_LIST_CAP]
     unsigned long long* big_tab;  // [2^BIG_TAB_BITS], all-ones = empty
     uint32_t one_round, per_round;  // LEAF_ONE_ROUND / LEAF_PER_ROUND (a testing knob lowers them: MDD_SUBSTR_LEAF_ROUND)
+    const unsigned long long* n_ent;  // entries handed out by emit_kernel (whole chunks: an upper bound of the windows sorted)
 };
+// With the candidate filter a pass may sort a few percent of the windows: 2^22 leaves of ten entries cost what 2^22 leaves of
+// 500 cost (ranges, table clear, round trips).  Adjacent leaves are adjacent in memory and the table matches on (d2, tag),
+// so 2^shift of them are grouped as ONE leaf until a leaf holds ~256-512 entries.  Every wave derives the same shift.
+__device__ __forceinline__ uint32_t leaf_merge_shift(const LeafArgs& A) {
+    const unsigned long long ne = *A.n_ent;
+    uint32_t shift = 0;
+    while (shift < 8u && (ne >> (D1_BITS + D2_BITS - shift)) < 256ull) shift++;
+    return shift;
+}
 constexpr uint32_t LEAF_ONE_ROUND = 640;  // a leaf (slice) up to this many windows is grouped in one go (the table holds 768 distinct)
 constexpr uint32_t LEAF_PER_ROUND = 448;  // beyond: rounds of about this many
 constexpr uint32_t BIG_LEAF = 16384;      // a leaf above this many windows is sliced over all waves
@@ -555,14 +678,6 @@ constexpr int BIG_TAB_BITS = 20;
 //     different (a tag collision: the 17 tag bits that vary inside a leaf meet by chance about once per leaf) -> go on
 //     probing, verifying on the way.  A slot's CONTENT never changes once claimed, and every window of one content walks
 //     the same probe sequence, so deferring cannot split a group of equal windows over two slots.
-// wave_sync() without its fences, which make the compiler wait for the global loads in flight (the next leaf's entries)
-// as well.  Between the lanes of ONE wave the LDS needs no fence -- DS instructions of a wave execute in issue order --
-// only the compiler must keep its hands off the order: a compiler-level memory barrier on both sides of the wave barrier.
-__device__ __forceinline__ void lds_sync() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
 constexpr int LEAF_CH = 10;     // entries per lane and chunk: 640 = LEAF_ONE_ROUND, above nearly every leaf's size
 constexpr int LEAF_ILP = 1;     // entries a lane inserts side by side (2 measured: 29.3 vs 29.5 ms, no gain)
 constexpr int CAND_CAP = 128;   // candidate list entries (whole turns of 64 are drained when a step could overflow it); 256 cost
@@ -746,11 +861,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const uint32_t lane = lane_id();
     const uint64_t n_waves = gridDim.x;
     LeafWave W(L, A, lane);
+    const uint32_t mshift = leaf_merge_shift(A);
+    A.n_leaves >>= mshift;
     auto leaf_range = [&](uint64_t leaf, uint64_t& lo, uint64_t& hi) {
         lo = hi = 0;
         if (leaf < A.n_leaves) {
-            lo = A.off2[leaf];
-            hi = A.off2[leaf + 1];
+            lo = A.off2[leaf << mshift];
+            hi = A.off2[(leaf + 1) << mshift];
         }
     };
 #ifdef MDD_LEAF_PROF
@@ -819,10 +936,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     LeafWave W(L, A, lane);
     unsigned int n_big = *A.n_big;
     if (n_big > BIG_LIST_CAP) n_big = BIG_LIST_CAP;
+    const uint32_t mshift = leaf_merge_shift(A);  // the numbering leaf_kernel queued the leaves under
+    A.n_leaves >>= mshift;
     for (unsigned int b = 0; b < n_big; b++) {
         const uint32_t leaf = A.big_list[b];
         if (leaf >= A.n_leaves) continue;
-        const uint64_t lo = A.off2[leaf], hi = A.off2[leaf + 1];
+        const uint64_t lo = A.off2[(uint64_t)leaf << mshift], hi = A.off2[((uint64_t)leaf + 1) << mshift];
         const uint64_t n_slices = (hi - lo + BIG_SLICE - 1) / BIG_SLICE;
         for (uint64_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
             const uint64_t slo = lo + sl * BIG_SLICE, shi = slo + BIG_SLICE < hi ? slo + BIG_SLICE : hi;
@@ -853,17 +972,15 @@ constexpr uint32_t AN_C0 = 0x9E3779B1u, AN_C1 = 0x85EBCA77u, AN_C2 = 0xC2B2AE3Du
 __device__ __forceinline__ uint32_t lane_up(uint32_t x, uint32_t lane, uint32_t n) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + n) & 63u) << 2), (int)x);
 }
-// 64-bit key of the 32 bytes whose dwords are w[0..7]: two multiply-with-carry chains over the even and the odd dwords,
-// one v_xor + one v_mad_u64_u32 per dword.  Any function of the BYTES would do for exactness; this one is cheap.
+// 64-bit key of the 32 bytes whose dwords are w[0..7]: two multiply-with-carry chains over dwords 0-3 and 4-7,
+// one v_xor + one v_mad_u64_u32 per PAIR of dwords.  Any function of the BYTES would do for exactness; this one is cheap.
 __device__ __forceinline__ uint64_t anchor_key(const uint32_t (&w)[8]) {
-    uint64_t a = (uint64_t)(w[0] ^ 0x243F6A88u) * AN_C0 + 0x13198A2E03707344ull;
-    uint64_t b = (uint64_t)(w[1] ^ 0xA4093822u) * AN_C1 + 0x299F31D0082EFA98ull;
-    a = (uint64_t)((uint32_t)a ^ w[2]) * AN_C1 + (a >> 32);
-    b = (uint64_t)((uint32_t)b ^ w[3]) * AN_C0 + (b >> 32);
-    a = (uint64_t)((uint32_t)a ^ w[4]) * AN_C2 + (a >> 32);
-    b = (uint64_t)((uint32_t)b ^ w[5]) * AN_C3 + (b >> 32);
-    a = (uint64_t)((uint32_t)a ^ w[6]) * AN_C3 + (a >> 32);
-    b = (uint64_t)((uint32_t)b ^ w[7]) * AN_C2 + (b >> 32);
+    // a' = (lo(a) ^ w_even) * C + (w_odd : hi(a)): the odd dword rides in the high half of the addend and meets a multiplier
+    // one step later (the last ones in the final fold)
+    uint64_t a = (uint64_t)(w[0] ^ 0x243F6A88u) * AN_C0 + (((uint64_t)w[1] << 32) | 0x03707344u);
+    uint64_t b = (uint64_t)(w[4] ^ 0xA4093822u) * AN_C1 + (((uint64_t)w[5] << 32) | 0x082EFA98u);
+    a = (uint64_t)((uint32_t)a ^ w[2]) * AN_C2 + (((uint64_t)w[3] << 32) | (a >> 32));
+    b = (uint64_t)((uint32_t)b ^ w[6]) * AN_C3 + (((uint64_t)w[7] << 32) | (b >> 32));
     const uint64_t u = a ^ ((b << 32) | (b >> 32));
     return (uint64_t)(uint32_t)u * AN_C0 + (uint64_t)(uint32_t)(u >> 32) * 0x9FB21C651E98DF25ull;
 }
@@ -924,7 +1041,7 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) anchor_kernel(AnchorArgs A) {
     for (;; item++) {
         if (item >= batch_end) {
             const uint64_t want = (total > item ? total - item : 0) >> A.batch_shift;
-            const uint32_t n = want < 1u ? 1u : (want > 16u ? 16u : (uint32_t)want);
+            const uint32_t n = want < 1u ? 1u : (want > 32u ? 32u : (uint32_t)want);
             item = fetch(n);
             if (item >= total) break;
             batch_end = item + n < total ? item + n : total;
@@ -1403,9 +1520,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
                             }
                         }
                         // verified repeats are repeats whatever becomes of the group
-#pragma unroll 1
-                        for (uint32_t u = 0; u < 19; u++)
-                            if ((marks >> u) & 1u) A.dup[a - 18 + u] = 1;
+                        if (marks) {  // whole dwords where all four bytes are marked (the marks of a run are), bytes elsewhere:
+                                      // other waves only ever write ones too
+                            const uint64_t p0 = a - 18;
+                            const uint32_t sh = (uint32_t)p0 & 3u;
+                            const uint32_t m22 = marks << sh;  // bit 4 k + j: byte j of dword (p0 >> 2) + k
+                            uint32_t* dw = reinterpret_cast<uint32_t*>(A.dup) + (p0 >> 2);
+#pragma unroll
+                            for (uint32_t k = 0; k < 6; k++) {
+                                const uint32_t nib = (m22 >> (4 * k)) & 0xFu;
+                                if (nib == 0xFu && ((p0 >> 2) + k + 1) * 4 <= A.text_bytes) {
+                                    dw[k] = 0x01010101u;
+                                } else if (nib) {
+#pragma unroll
+                                    for (uint32_t j = 0; j < 4; j++)
+                                        if ((nib >> j) & 1u) A.dup[(((p0 >> 2) + k) << 2) + j] = 1;
+                                }
+                            }
+                        }
                     }
                     if (!vouch) atomicOr(&L.fb[slot >> 5], 1u << (slot & 31u));
                 }
@@ -1643,7 +1775,7 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     E.hist1 = W.hist1;
     E.overflow = W.counters + 7;
     uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
-    while ((1ull << E.batch_shift) < w * 4) E.batch_shift++;
+    while ((1ull << E.batch_shift) < w / 4) E.batch_shift++;  // (batches of 32 until ~8 items per wave are left: see emit_kernel)
     hipLaunchKernelGGL(anchor_kernel, dim3((unsigned)((w + EMIT_WAVES - 1) / EMIT_WAVES)), dim3(64 * EMIT_WAVES), 0, st, E);
     HIP_TRY(hipGetLastError());
     {
@@ -1735,7 +1867,11 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     E.d1 = d1_ws;
     E.cand = cand;
     uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
-    while ((1ull << E.batch_shift) < w * 4) E.batch_shift++;
+    // guided self-scheduling: a claim takes (items left) >> batch_shift items, at most max_batch.  Without the filter an item
+    // is ~30 rounds of hashing and single items at the end balance the waves; with it an item is a few microseconds and the
+    // claims themselves (11 ns each, serialised on one address) were 2 of the kernel's 5 ms
+    E.max_batch = cand ? 64u : 16u;
+    while ((1ull << E.batch_shift) < (cand ? w / 4 : w * 4)) E.batch_shift++;
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((w + EMIT_WAVES - 1) / EMIT_WAVES)), dim3(64 * EMIT_WAVES), 0, st, E);
     HIP_TRY(hipGetLastError());
     {
@@ -1758,6 +1894,7 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     L.big_tab = W.big_tab;
     L.one_round = LEAF_ONE_ROUND;
     L.per_round = LEAF_PER_ROUND;
+    L.n_ent = W.counters;
     if (const char* knob = getenv("MDD_SUBSTR_LEAF_ROUND")) {  // testing: "one_round,per_round" below the defaults forces the multi-round path
         unsigned a = 0, b = 0;
         if (sscanf(knob, "%u,%u", &a, &b) == 2 && a >= 1 && a <= LEAF_ONE_ROUND && b >= 1 && b <= LEAF_PER_ROUND) {
