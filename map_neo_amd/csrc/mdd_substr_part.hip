@@ -966,6 +966,7 @@ constexpr uint32_t AN_MINWIN = AN_KG + AN_SPAN - 1;   // = 50: the smallest wind
 constexpr uint32_t AN_LANES = 50;                     // lanes of a step whose 4 positions get a window minimum: their windows reach
                                                       // position 4 * 49 + 3 + 18 = 217 (lane 54), whose k-gram ends in lane 62's dword
 static_assert(AN_MINWIN == 50, "mdd_substr_candidates: the filter is defined for windows of at least 50 code points");
+constexpr int AN_D1_BITS = 9;                         // level-1 digit of an anchor (a window entry has 11)
 constexpr uint32_t AN_C0 = 0x9E3779B1u, AN_C1 = 0x85EBCA77u, AN_C2 = 0xC2B2AE3Du, AN_C3 = 0x27D4EB2Fu;
 
 // lane l reads x of lane l + n (the top n lanes read the bottom ones: their positions are never used)
@@ -984,13 +985,13 @@ __device__ __forceinline__ uint64_t anchor_key(const uint32_t (&w)[8]) {
     const uint64_t u = a ^ ((b << 32) | (b >> 32));
     return (uint64_t)(uint32_t)u * AN_C0 + (uint64_t)(uint32_t)(u >> 32) * 0x9FB21C651E98DF25ull;
 }
-// what is sorted: [d2:11 | tag:17 | pos:36] like a window entry; d1 has 8 bits here (256 partitions x 2048 = 2^19 leaves of
-// ~400 anchors).  The ORDER among a window's k-grams uses bits 31..8 of the key, so d1 / d2 / tag avoid the top of the low
+// what is sorted: [d2:11 | tag:17 | pos:36] like a window entry; d1 has 9 bits here (512 partitions x 2048 = 2^20 leaves of
+// ~200 anchors: small leaves mean small LDS tables and many resident waves for anchor_resolve_kernel, which waits on memory).  The ORDER among a window's k-grams uses bits 31..8 of the key, so d1 / d2 / tag avoid the top of the low
 // half (anchors are minima: those bits are mostly zero).
-__device__ __forceinline__ uint32_t anchor_d1(uint64_t key) { return (uint32_t)(key >> 56); }
+__device__ __forceinline__ uint32_t anchor_d1(uint64_t key) { return (uint32_t)(key >> (64 - AN_D1_BITS)); }
 __device__ __forceinline__ uint64_t anchor_entry(uint64_t key, uint64_t pos) {
     const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-    const uint64_t d2tag = ((uint64_t)(hi & 0x00FFFFFFu) << 4) | ((lo >> 8) & 0xFu);  // 24 + 4 = 11 + 17 bits
+    const uint64_t d2tag = ((uint64_t)(hi & 0x007FFFFFu) << 5) | ((lo >> 8) & 0x1Fu);  // 23 + 5 = 11 + 17 bits below the 9 of d1
     return (d2tag << POS_BITS) | pos;
 }
 
@@ -1327,20 +1328,26 @@ __global__ void __launch_bounds__(256) vmap_kernel(const uint8_t* __restrict__ t
 // vouch for -- a byte >= 0x80 in the region (windows are then longer than 50 bytes), a group above RS_GROUP members, a leaf
 // too big for the table, an anchor in the first 20 bytes of the text -- is flagged, WITH ITS WHOLE GROUP, for the window
 // sort (mdd_substr_mark_sorted): both copies of a repeated window are then sorted, as the filter alone would have it.
-constexpr uint32_t RS_MAX = 768;     // anchors per leaf that go through the table (1024 slots)
+constexpr uint32_t RS_SLOTS = 512;   // LDS table slots per leaf
+constexpr uint32_t RS_MAX = 384;     // anchors per leaf that go through the table (a leaf holds ~200)
 constexpr uint32_t RS_CH = RS_MAX / 64;
-constexpr uint32_t RS_GROUP = 32;    // chain steps a member takes before its group is handed to the window sort
+constexpr uint32_t RS_GROUP = 32;    // a group (anchors of one key) above this many members is handed to the window sort
 constexpr uint32_t RS_LIST = 128;    // work list: members with an earlier anchor in their group
-constexpr uint32_t RS_NIL = 0xFFFFu;
+constexpr uint32_t RS_NIL = 511u;    // end of a chain (member indices stay below RS_MAX)
+static_assert(RS_MAX <= RS_NIL, "member index and NIL share 9 bits");
+__device__ __forceinline__ uint32_t rs_home(unsigned long long val) { return ((uint32_t)(val >> POS_BITS) * 0x9E3779B1u) >> (32 - 9); }
+static_assert(RS_SLOTS == 512, "rs_home yields 9 bits");
 struct ResolveLds {
-    unsigned long long tab[LEAF_SLOTS];  // [d2 | tag | position] of the group's lowest anchor; all-ones = empty
-    uint32_t head[LEAF_SLOTS];           // index (inside the leaf) of the group's most recently chained member
+    unsigned long long tab[RS_SLOTS];  // [d2 | tag | position] of the group's lowest anchor; all-ones = empty
+    uint32_t head[RS_SLOTS];           // [members : 23 | index (inside the leaf) of the most recently chained member : 9]
     uint16_t next[RS_MAX];
-    uint32_t fb[LEAF_SLOTS / 32];        // groups handed to the window sort
+    uint32_t fb[RS_SLOTS / 32];        // groups handed to the window sort
     unsigned long long lval[RS_LIST];
     uint16_t lslot[RS_LIST];
+    uint16_t lidx[RS_LIST];              // index of the member inside the leaf
+    uint32_t clone[RS_MAX / 32];         // members that add nothing to their group's lowest anchor (see drain)
 };
-constexpr unsigned RS_WAVES_PER_CU = 10;
+constexpr unsigned RS_WAVES_PER_CU = 18;
 static_assert(RS_WAVES_PER_CU * sizeof(ResolveLds) <= 160 * 1024, "the resolve kernel's workgroups must all be resident");
 struct ResolveArgs {
     const uint64_t* ent;
@@ -1414,12 +1421,12 @@ __device__ __forceinline__ uint32_t region_match(const uint32_t (&Ra)[18], const
     return (0x7FFFFu >> (18u - r)) & (0x7FFFFu << (18u - l)) & 0x7FFFFu;  // bits 18 - l .. r
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) anchor_resolve_kernel(ResolveArgs A) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) anchor_resolve_kernel(ResolveArgs A) {
     __shared__ ResolveLds L;
     const uint32_t lane = lane_id();
     auto find_slot = [&](unsigned long long val) -> uint32_t {  // the slot of val's group (val has been inserted)
-        uint32_t slot = leaf_home(val);
-        for (uint32_t probe = 0; probe < LEAF_SLOTS && (L.tab[slot] >> POS_BITS) != (val >> POS_BITS); probe++) slot = (slot + 1) & (LEAF_SLOTS - 1);
+        uint32_t slot = rs_home(val);
+        for (uint32_t probe = 0; probe < RS_SLOTS && (L.tab[slot] >> POS_BITS) != (val >> POS_BITS); probe++) slot = (slot + 1) & (RS_SLOTS - 1);
         return slot;
     };
     for (uint32_t leaf = blockIdx.x; leaf < A.n_leaves; leaf += gridDim.x) {
@@ -1439,11 +1446,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
             e[k] = i < hi ? A.ent[i] : ENT_INVALID;
         }
 #pragma unroll
-        for (int i = 0; i < LEAF_SLOTS / 64; i++) {
+        for (int i = 0; i < RS_SLOTS / 64; i++) {
             L.tab[i * 64 + lane] = ENT_INVALID;
-            L.head[i * 64 + lane] = RS_NIL;
+            L.head[i * 64 + lane] = RS_NIL;  // no members, empty chain
         }
-        if (lane < LEAF_SLOTS / 32) L.fb[lane] = 0;
+        if (lane < RS_SLOTS / 32) L.fb[lane] = 0;
+        if (lane < RS_MAX / 32) L.clone[lane] = 0;
         lds_sync();
         // ---- 1. groups: the slot keeps the lowest anchor of its key, the chain every member
 #pragma unroll 1
@@ -1453,18 +1461,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
             for (uint32_t j = 0; j + 1 < RS_CH; j++) e[j] = e[j + 1];
             e[RS_CH - 1] = ENT_INVALID;
             if (val == ENT_INVALID) continue;
-            uint32_t slot = leaf_home(val);
-            for (uint32_t probe = 0; probe < LEAF_SLOTS; probe++) {
+            uint32_t slot = rs_home(val);
+            for (uint32_t probe = 0; probe < RS_SLOTS; probe++) {
                 const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
                 if (cur == ENT_INVALID) break;
                 if ((cur >> POS_BITS) == (val >> POS_BITS)) {
                     if (val < cur) atomicMin(&L.tab[slot], val);
                     break;
                 }
-                slot = (slot + 1) & (LEAF_SLOTS - 1);
+                slot = (slot + 1) & (RS_SLOTS - 1);
             }
+            // chain this member in: head = [members so far : 23 | most recent member : 9], updated as one word
             const uint32_t idx = k * 64 + lane;
-            L.next[idx] = (uint16_t)atomicExch(&L.head[slot], idx);
+            uint32_t old = L.head[slot];
+            for (;;) {
+                const uint32_t seen = atomicCAS(&L.head[slot], old, (((old >> 9) + 1u) << 9) | idx);
+                if (seen == old) break;
+                old = seen;
+            }
+            L.next[idx] = (uint16_t)(old & RS_NIL);
         }
         lds_sync();
         // ---- 2. members with an earlier anchor in their group, 64 at a time with every lane busy
@@ -1473,82 +1488,85 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
             lds_sync();
             uint32_t base = 0;
             for (; all ? base < n_list : base + 64 <= n_list; base += 64) {
-                if (base + lane < n_list) {
-                    const unsigned long long val = L.lval[base + lane];
-                    const uint32_t slot = L.lslot[base + lane];
-                    const uint64_t a = val & POS_M;
-                    bool vouch = a >= 20 && a + 52 <= A.text_bytes + MDD_TEXT_PAD;
-                    uint32_t left = 0;  // hashed windows of this anchor that no earlier member explains yet
-                    if (vouch) {
-                        uint32_t Ra[18];
-                        load_region(A.text, a, Ra);
-                        const uint32_t va = vmask19(A.vmap, a - 18);
-                        uint32_t hi_or = 0;
+                // ---- A: this member against the group's lowest anchor
+                const bool active = base + lane < n_list;
+                unsigned long long val = 0;
+                uint32_t slot = 0, idx = 0;
+                if (active) val = L.lval[base + lane], slot = L.lslot[base + lane], idx = L.lidx[base + lane];
+                const uint64_t a = val & POS_M;
+                const uint64_t b = active ? (L.tab[slot] & POS_M) : 0;  // (b < a: a member of the work list is not its group's lowest)
+                // a group above max_group members is the window sort's business as a whole (one member with an unexplained window
+                // hands it over anyway, and in a group that large one always has): nothing is loaded for it
+                const uint32_t members = active ? L.head[slot] >> 9 : 0u;
+                bool vouch = active && members <= A.max_group && a >= 20 && b >= 20 && a + 52 <= A.text_bytes + MDD_TEXT_PAD;
+                uint32_t Ra[18], left = 0, marks = 0;
+                if (vouch) {
+                    load_region(A.text, a, Ra);
+                    const uint32_t va = vmask19(A.vmap, a - 18);
+                    uint32_t hi_or = 0;
 #pragma unroll
-                        for (int k = 0; k < 18; k++) hi_or |= Ra[k];
-                        vouch = (hi_or & 0x80808080u) == 0u;
-                        left = va;
-                        uint32_t marks = 0;
-                        if (vouch && left) {
-                            const uint64_t b = L.tab[slot] & POS_M;  // the group's lowest anchor first
-                            if (b < a && b >= 20) {
-                                uint32_t Rb[18];
-                                load_region(A.text, b, Rb);
-                                const uint32_t m = region_match(Ra, Rb) & vmask19(A.vmap, b - 18) & va;
-                                marks |= m;
-                                left &= ~m;
-                            } else if (b < 20) {
-                                vouch = false;
-                            }
-                            uint32_t steps = 0;
-                            for (uint32_t i = L.head[slot]; vouch && left && i != RS_NIL; i = L.next[i]) {
-                                if (++steps > A.max_group) {
-                                    vouch = false;
-                                    break;
-                                }
-                                const uint64_t b2 = A.ent[lo + i] & POS_M;
-                                if (b2 >= a || b2 == b) continue;
-                                if (b2 < 20) {
-                                    vouch = false;
-                                    break;
-                                }
-                                uint32_t Rb[18];
-                                load_region(A.text, b2, Rb);
-                                const uint32_t m = region_match(Ra, Rb) & vmask19(A.vmap, b2 - 18) & va;
-                                marks |= m;
-                                left &= ~m;
-                            }
+                    for (int k = 0; k < 18; k++) hi_or |= Ra[k];
+                    vouch = (hi_or & 0x80808080u) == 0u;
+                    left = va;
+                    if (vouch && left) {
+                        uint32_t Rb[18];
+                        load_region(A.text, b, Rb);
+                        const uint32_t vb = vmask19(A.vmap, b - 18);
+                        const uint32_t rm = region_match(Ra, Rb);
+                        marks = rm & vb & va;
+                        left = va & ~marks;
+                        // a member whose 68 bytes equal the lowest anchor's, with no hashed window the lowest lacks, can explain
+                        // nothing the lowest cannot: the walks below skip it
+                        if (rm == 0x7FFFFu && (va & ~vb) == 0u) atomicOr(&L.clone[idx >> 5], 1u << (idx & 31u));
+                    }
+                }
+                lds_sync();  // (the clone bits of this turn's members are in place)
+                // ---- B: what the lowest anchor does not explain is tried on the other earlier members
+                if (vouch && left) {
+                    const uint32_t va = left | marks;
+                    for (uint32_t i = L.head[slot] & RS_NIL; left && i != RS_NIL; i = L.next[i]) {
+                        if ((L.clone[i >> 5] >> (i & 31u)) & 1u) continue;
+                        const uint64_t b2 = A.ent[lo + i] & POS_M;
+                        if (b2 >= a || b2 == b) continue;
+                        if (b2 < 20) {
+                            vouch = false;
+                            break;
                         }
-                        // verified repeats are repeats whatever becomes of the group
-                        if (marks) {  // whole dwords where all four bytes are marked (the marks of a run are), bytes elsewhere:
-                                      // other waves only ever write ones too
-                            const uint64_t p0 = a - 18;
-                            const uint32_t sh = (uint32_t)p0 & 3u;
-                            const uint32_t m22 = marks << sh;  // bit 4 k + j: byte j of dword (p0 >> 2) + k
-                            uint32_t* dw = reinterpret_cast<uint32_t*>(A.dup) + (p0 >> 2);
+                        uint32_t Rb[18];
+                        load_region(A.text, b2, Rb);
+                        const uint32_t m = region_match(Ra, Rb) & vmask19(A.vmap, b2 - 18) & va;
+                        marks |= m;
+                        left &= ~m;
+                    }
+                }
+                // verified repeats are repeats whatever becomes of the group
+                if (marks) {  // whole dwords where all four bytes are marked (the marks of a run are), bytes elsewhere:
+                              // other waves only ever write ones too
+                    const uint64_t p0 = a - 18;
+                    const uint32_t sh = (uint32_t)p0 & 3u;
+                    const uint32_t m22 = marks << sh;  // bit 4 k + j: byte j of dword (p0 >> 2) + k
+                    uint32_t* dw = reinterpret_cast<uint32_t*>(A.dup) + (p0 >> 2);
 #pragma unroll
-                            for (uint32_t k = 0; k < 6; k++) {
-                                const uint32_t nib = (m22 >> (4 * k)) & 0xFu;
-                                if (nib == 0xFu && ((p0 >> 2) + k + 1) * 4 <= A.text_bytes) {
-                                    dw[k] = 0x01010101u;
-                                } else if (nib) {
+                    for (uint32_t k = 0; k < 6; k++) {
+                        const uint32_t nib = (m22 >> (4 * k)) & 0xFu;
+                        if (nib == 0xFu && ((p0 >> 2) + k + 1) * 4 <= A.text_bytes) {
+                            dw[k] = 0x01010101u;
+                        } else if (nib) {
 #pragma unroll
-                                    for (uint32_t j = 0; j < 4; j++)
-                                        if ((nib >> j) & 1u) A.dup[(((p0 >> 2) + k) << 2) + j] = 1;
-                                }
-                            }
+                            for (uint32_t j = 0; j < 4; j++)
+                                if ((nib >> j) & 1u) A.dup[(((p0 >> 2) + k) << 2) + j] = 1;
                         }
                     }
-                    if (!vouch) atomicOr(&L.fb[slot >> 5], 1u << (slot & 31u));
                 }
+                if (active && !vouch) atomicOr(&L.fb[slot >> 5], 1u << (slot & 31u));
             }
             const uint32_t rest = base < n_list ? n_list - base : 0u;
             if (rest && base) {
                 unsigned long long v = 0;
-                uint16_t sl = 0;
-                if (lane < rest) v = L.lval[base + lane], sl = L.lslot[base + lane];
+                uint16_t sl = 0, ix = 0;
+                if (lane < rest) v = L.lval[base + lane], sl = L.lslot[base + lane], ix = L.lidx[base + lane];
                 lds_sync();
-                if (lane < rest) L.lval[lane] = v, L.lslot[lane] = sl;
+                if (lane < rest) L.lval[lane] = v, L.lslot[lane] = sl, L.lidx[lane] = ix;
             }
             lds_sync();
             n_list = rest;
@@ -1568,6 +1586,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
                 const uint32_t at = n_list + below(wb);
                 L.lval[at] = val;
                 L.lslot[at] = (uint16_t)slot;
+                L.lidx[at] = (uint16_t)(i - lo);
             }
             n_list += (uint32_t)__popcll(wb);
             if (n_list > RS_LIST - 64) drain(false);
@@ -1575,7 +1594,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
         drain(true);
         // ---- 3. groups this pass cannot vouch for: every member is flagged for the window sort
         bool any_fb = false;
-        if (lane < LEAF_SLOTS / 32) any_fb = L.fb[lane] != 0u;
+        if (lane < RS_SLOTS / 32) any_fb = L.fb[lane] != 0u;
         if (__ballot(any_fb)) {
             for (uint64_t i = lo + lane; i < hi; i += 64) {
                 const unsigned long long val = A.ent[i];
@@ -1784,7 +1803,7 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     }
     uint8_t* flag = reinterpret_cast<uint8_t*>(ent_b);
     HIP_TRY(hipMemsetAsync(flag, 0, text_bytes + 64, st));
-    const uint32_t n_leaves_a = 256u * (uint32_t)BINS2;  // anchors carry an 8-bit level-1 digit
+    const uint32_t n_leaves_a = (1u << AN_D1_BITS) * (uint32_t)BINS2;  // anchors carry a 9-bit level-1 digit
     if (resolve && !getenv("MDD_SUBSTR_NO_RESOLVE")) {     // (the knob: A/B runs and tests of the filter-only path)
         ResolveArgs R{};
         R.ent = ent_a;
