@@ -167,8 +167,9 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
                               "algorithmic_bytes": 2 * text_bytes + int(po[-1].item()) + 36 * n_par,
                               "hbm_frac": (2 * text_bytes + int(po[-1].item()) + 36 * n_par) / ms / 1e6 / HBM,
                               "note": "algorithmic = text read to cut + to hash, survivors written, 36 B of unit ranges / keys / "
-                                      "table per paragraph; the implementation reads the text 5 times (count, units, hash, "
-                                      "compact count, compact write)"}
+                                      "table per paragraph; the implementation reads the text 4 times (count, units, hash, write "
+                                      "-- round 2: 5; the per-document sums now come from the units, mdd_para_doc_sums, and a "
+                                      "document that keeps every paragraph is copied)"}
     if with_cpu:
         from oracle import ref_exact
         k = 20000
@@ -196,18 +197,24 @@ def stage_benchmarks(eng, text, offsets, text_bytes, with_cpu=True):
     alg = sb + 2 * sb + int(so2[-1].item())
     out["exact_substr_dedup"].update({"algorithmic_bytes": alg, "hbm_frac": alg / ms / 1e6 / HBM})
     if eng.last_substr_method == "sorted":
-        # implementation bytes, per window: entry written + d1 (10 B), read and rewritten by two scatter levels (2 x 16 B + 2 B),
-        # read by the count pass and by the leaves (16 B), ~15 % of the windows verified on two 64-byte lines; text read by
-        # emit and by the two compaction passes, dup marks written and read, survivors written
-        impl = n_win * (10 + 34 + 16) + int(0.15 * n_win) * 256 + 3 * sb + 3 * sb + int(so2[-1].item())
+        cand = eng.last_substr_candidates
+        n_sort = cand[0] if cand else n_win
+        # implementation bytes (a model; the measured HBM traffic per kernel is in profiles/r3*_pmc_substr*): per SORTED entry
+        # 10 B written (entry + d1), 34 B through the two scatter levels, 16 B read by the count pass and the leaves;
+        # with the filter the anchors (one per ~10 windows) are such entries and only n_sort windows follow them; the text is
+        # read by the map of window starts, the anchor kernel, emit (documents with a candidate) and the two compaction
+        # passes; the flag / map / mark arrays (one byte per text byte) are written and read ~7 times in all
+        n_anchor = n_win // 10 if cand else 0
+        impl = (n_anchor + n_sort) * 60 + (5 if cand else 3) * sb + (7 if cand else 3) * sb + int(so2[-1].item())
         out["exact_substr_dedup"].update({
+            "windows": n_win, "windows_to_window_sort": n_sort, "anchors_model": n_anchor,
             "implementation_bytes_model": impl, "implementation_hbm_frac": impl / ms / 1e6 / HBM,
-            "note": "windows sorted into 2^22 leaves (two LDS-sorted scatter levels) and grouped in LDS, bytes compared on tag "
-                    "matches.  hbm_frac prices the stage against what it must move (text in, marks, text out); the sort's own "
-                    "traffic is implementation_bytes_model (PMC, profiles/r3_pmc_bench/summary.json: ~216 GB per pass -- "
-                    "FETCH_SIZE doubled for the streaming kernels, at face value for leaf_kernel, whose reads are scattered 64-byte "
-                    "requests: the calibration kernels count 63.9 B per scattered 16-byte load).  Bounded by random DRAM accesses (~17.5 G/s of runs / "
-                    "~41 G scattered 64-byte requests/s): level-1 runs of 6 entries and two text lines per verified window"})
+            "note": "round 3: a window can only repeat when the 32-byte k-gram its bytes select (minimizer over its first 19 offsets) "
+                    "occurs twice, so the ANCHORS (one per ~10 windows) are sorted into 2^20 leaves instead of the windows; a repeated "
+                    "anchor is settled in its leaf by comparing the 68 bytes around it with the earlier anchors of its key (all 19 "
+                    "windows at once), and only what that cannot vouch for (keys with > 32 anchors, non-ASCII regions) reaches the "
+                    "window sort of round 2 (2^22 leaves, bytes compared on tag matches).  hbm_frac prices the stage against what it "
+                    "must move (text in, marks, text out); the method's own traffic is implementation_bytes_model"})
     else:
         out["exact_substr_dedup"].update({
             "random_atomics": n_win, "atomic_floor_ms": n_win / 17.5e9 * 1e3,

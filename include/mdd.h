@@ -271,10 +271,16 @@ int mdd_removed_mask(mdd_ctx* ctx, const uint32_t* labels, uint64_t first, uint6
  * tag; a tag match is confirmed by comparing the bytes inside the kernels, so the result is exact.
  * *n_coll (device u64) counts the tag matches that were different bytes (statistics).
  * Workspaces: key_scratch u64[n_units]; table u64[tab_size], tab_size a power of two
- * >= 2*n_units.  avg_unit_bytes picks thread-per-unit (< 256) or wave-per-unit hashing. */
+ * >= 2*n_units.  avg_unit_bytes picks the hash kernel: a thread per unit (< 64), eight lanes per unit (< 2048) or a wave
+ * per unit; all three compute the same key. */
 int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* ubeg, const uint64_t* uend, uint64_t n_units,
                     uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table, uint64_t tab_size,
                     uint32_t* first_of, uint64_t* n_coll);
+/* the same, and unit_cps[u] (u32[n_units]) = code points of unit u, counted by the hash pass that reads the unit's bytes
+ * anyway (paragraph dedup needs them for PAR:29's length filter: mdd_para_doc_sums) */
+int mdd_exact_group_cps(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* ubeg, const uint64_t* uend,
+                        uint64_t n_units, uint64_t avg_unit_bytes, int key_bits, uint64_t* key_scratch, uint64_t* table,
+                        uint64_t tab_size, uint32_t* first_of, uint64_t* n_coll, uint32_t* unit_cps);
 
 /* Paragraph dedup.  Replaces paragraph_dedup of
  * Matrix/english_data_clean_pipeline/dedup/Paragraph_Deduplication/paragraph.py:15-30 around
@@ -285,8 +291,12 @@ int mdd_exact_group(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *            PAR:18-23 (first_of[u] == u <=> the paragraph survives).
  *   compact_count: kept_bytes[d] / kept_cps[d] = bytes / code points of "\n".join(surviving
  *            paragraphs of d) (PAR:26-27), has_unit[d] = 1 when at least one survives;
+ *   doc_sums (round 3): the same three per-document results as compact_count, computed from the UNITS instead of the text
+ *            (lengths from ubeg / uend, code points from mdd_exact_group_cps: ~28 bytes per paragraph instead of the
+ *            document), plus whole_doc[d] = 1 when every paragraph of d survives (the output is then the document itself);
  *   compact_write: that text for every document with keep_doc[d] != 0 (the caller applies PAR:29) at
- *            out_text[out_offsets[d] ..); nothing is written at or beyond out_capacity. */
+ *            out_text[out_offsets[d] ..); nothing is written at or beyond out_capacity.  whole_doc (may be NULL): documents
+ *            flagged there are copied instead of being re-assembled paragraph by paragraph. */
 int mdd_para_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                    uint64_t* units_per_doc);
 int mdd_para_units(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
@@ -296,7 +306,10 @@ int mdd_para_compact_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
                            uint64_t* kept_cps, uint8_t* has_unit);
 int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                            const uint64_t* unit_base, uint64_t n_units, const uint32_t* first_of, const uint8_t* keep_doc,
-                           const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity);
+                           const uint64_t* out_offsets, uint8_t* out_text, uint64_t out_capacity, const uint8_t* whole_doc);
+int mdd_para_doc_sums(mdd_ctx* ctx, const uint64_t* offsets, uint64_t n_docs, uint64_t text_bytes, const uint64_t* unit_base,
+                      uint64_t n_units, const uint64_t* ubeg, const uint64_t* uend, const uint32_t* unit_cps, const uint32_t* first_of,
+                      uint64_t* kept_bytes, uint64_t* kept_cps, uint8_t* has_unit, uint8_t* whole_doc);
 
 /* Exact substring dedup.  Replaces text2hash + groupByKey +
  * get_remove_list + remove_dup_content + the min_length filter of

@@ -6,8 +6,10 @@
 //   :29     length >= min_len                             -> caller, from kept_cps
 // One wave per document, 64 bytes per step; a byte's paragraph index is unit_base[d] + the
 // newlines before it, so ballots + popcounts place every unit boundary and every surviving byte
-// without scans or LDS.  HBM-bound: the text is read four times (count, units, compact count,
-// compact write) and the survivors written once.
+// without scans or LDS.  HBM-bound.  Round 3: the text is read three times plus once by the grouping (count, units, hash,
+// write) instead of five: the per-document sums come from the UNITS (mdd_para_doc_sums: lengths from the unit ranges, code
+// points counted by the grouping's hash pass, ~230 MB instead of the text), and a document all of whose paragraphs survive
+// -- nearly every document -- leaves the write pass as a straight copy.
 #include "mdd_common.h"
 
 namespace {
@@ -275,20 +277,56 @@ __global__ void __launch_bounds__(256) para_compact_write4_kernel(const uint8_t*
                                                                   const uint64_t* __restrict__ unit_base, uint64_t n_units,
                                                                   const uint32_t* __restrict__ first_of, const uint8_t* __restrict__ keep_doc,
                                                                   const uint64_t* __restrict__ out_offs, uint8_t* __restrict__ out_text,
-                                                                  uint64_t out_cap) {
+                                                                  uint64_t out_cap, const uint8_t* __restrict__ whole_doc) {
     const uint32_t lane = lane_id();
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
     auto kept_unit = [&](uint64_t u) -> bool { return u < n_units && first_of[u] == (uint32_t)u; };
-    for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
-        if (!keep_doc[d]) continue;
-        uint64_t b, e;
-        doc_range(offs, d, text_bytes, b, e);
+    auto rl64 = [](uint64_t x, uint32_t j) -> uint64_t {  // lane j's value (j wave-uniform)
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)j) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)j);
+    };
+    // 64 documents at a time: every lane fetches one document's range, verdicts, output offset and first paragraph, so the
+    // five dependent loads a document needs cost one round trip per 64 documents instead of one per document (a document
+    // that is copied whole is two steps of work: the kernel was waiting on those loads)
+    for (uint64_t D = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64; D < n; D += nw * 64) {
+        const uint64_t dl = D + lane;
+        uint64_t b_l = 0, e_l = 0, o_l = 0, u_l = 0;
+        bool keep_l = false, whole_l = false;
+        if (dl < n) {
+            keep_l = keep_doc[dl] != 0;
+            whole_l = whole_doc && whole_doc[dl] != 0;
+            doc_range(offs, dl, text_bytes, b_l, e_l);
+            o_l = out_offs[dl];
+            u_l = unit_base[dl];
+        }
+        const uint64_t wmask = __ballot(whole_l);
+        for (uint64_t km = __ballot(keep_l); km; km &= km - 1) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(km);
+        const uint64_t b = rl64(b_l, j), e = rl64(e_l, j);
+        if ((wmask >> j) & 1ull) {
+            // every paragraph survives ("\n".join of all of them = the document): a copy, four unaligned dwords in flight per lane
+            const uint64_t o = rl64(o_l, j), len = e - b;
+            for (uint64_t i = 4ull * lane; i < len; i += 1024) {
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint64_t q = i + 256ull * j;
+                    v[j] = q < len ? *reinterpret_cast<const mdd_u32_a1*>(text + b + q) : 0u;  // (over-read < 4 bytes: inside MDD_TEXT_PAD)
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint64_t q = i + 256ull * j;
+                    if (q < len) store_low_bytes(out_text, o + q, out_cap, v[j], len - q < 4 ? (uint32_t)(len - q) : 4u);
+                }
+            }
+            continue;
+        }
         const uint64_t w0 = b >> 2, w1 = b < e ? (e + 3) >> 2 : w0;
-        uint64_t u = unit_base[d];
-        uint64_t done = out_offs[d];  // next output position of the wave
-        bool any = false;             // a surviving paragraph ended in an earlier step
+        uint64_t u = rl64(u_l, j);
+        uint64_t done = rl64(o_l, j);  // next output position of the wave
+        bool any = false;              // a surviving paragraph ended in an earlier step
         for (uint64_t wi = w0; wi < w1; wi += 128) {
             uint32_t ww[2];
 #pragma unroll
@@ -362,10 +400,58 @@ __global__ void __launch_bounds__(256) para_compact_write4_kernel(const uint8_t*
                 u += __builtin_popcountll(B0) + 2 * __builtin_popcountll(B1) + 4 * __builtin_popcountll(B2);
             }
         }
+        }
     }
 }
 
+// per-document sums of the compaction from the units alone (no text): what para_compact_count4_kernel computes, for
+// callers that hold the units' ranges and code-point counts (mdd_exact_group_cps).  One thread per document.
+__global__ void __launch_bounds__(256) para_doc_sums_kernel(const uint64_t* __restrict__ offs, uint64_t n, uint64_t text_bytes,
+                                                            const uint64_t* __restrict__ unit_base, uint64_t n_units,
+                                                            const uint64_t* __restrict__ ubeg, const uint64_t* __restrict__ uend,
+                                                            const uint32_t* __restrict__ ucps, const uint32_t* __restrict__ first_of,
+                                                            uint64_t* kept_bytes, uint64_t* kept_cps, uint8_t* has_unit, uint8_t* whole_doc) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    uint64_t b, e;
+    doc_range(offs, d, text_bytes, b, e);
+    uint64_t u0 = unit_base[d], u1 = d + 1 < n ? unit_base[d + 1] : n_units;
+    u1 = u1 < n_units ? u1 : n_units;
+    u0 = u0 < u1 ? u0 : u1;
+    uint64_t ns = 0, kb = 0, kc = 0;
+    for (uint64_t u = u0; u < u1; u++)
+        if (first_of[u] == (uint32_t)u) {
+            uint64_t ue = uend[u], ub = ubeg[u];
+            ue = ue < text_bytes ? ue : text_bytes;
+            ub = ub < ue ? ub : ue;
+            ns++;
+            kb += ue - ub;
+            kc += ucps[u];
+        }
+    const uint64_t joins = ns ? ns - 1 : 0;
+    kept_bytes[d] = kb + joins;
+    kept_cps[d] = kc + joins;
+    has_unit[d] = ns != 0;
+    whole_doc[d] = ns != 0 && ns == u1 - u0 && kb + joins == e - b;  // nothing dropped: the output is the document itself
+}
+
 }  // namespace
+
+extern "C" int mdd_para_doc_sums(mdd_ctx* ctx, const uint64_t* offsets, uint64_t n_docs, uint64_t text_bytes, const uint64_t* unit_base,
+                                 uint64_t n_units, const uint64_t* ubeg, const uint64_t* uend, const uint32_t* unit_cps,
+                                 const uint32_t* first_of, uint64_t* kept_bytes, uint64_t* kept_cps, uint8_t* has_unit,
+                                 uint8_t* whole_doc) {
+    REQUIRE(ctx, "mdd_para_doc_sums: ctx is NULL");
+    if (n_docs == 0) return MDD_OK;
+    REQUIRE(offsets && unit_base && kept_bytes && kept_cps && has_unit && whole_doc && ((ubeg && uend && unit_cps && first_of) || n_units == 0),
+            "mdd_para_doc_sums: NULL buffer");
+    REQUIRE(n_docs <= MAX_ELEMS_PER_LAUNCH, "mdd_para_doc_sums: n_docs=%llu exceeds 2^32-256", (unsigned long long)n_docs);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(para_doc_sums_kernel, dim3(grid_for(n_docs, 256)), dim3(256), 0, ctx->stream, offsets, n_docs, text_bytes, unit_base,
+                       n_units, ubeg, uend, unit_cps, first_of, kept_bytes, kept_cps, has_unit, whole_doc);
+    HIP_TRY(hipGetLastError());
+    return MDD_OK;
+}
 
 extern "C" int mdd_para_count(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                               uint64_t* units_per_doc) {
@@ -421,7 +507,7 @@ extern "C" int mdd_para_compact_count(mdd_ctx* ctx, const uint8_t* text, uint64_
 extern "C" int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets,
                                       uint64_t n_docs, const uint64_t* unit_base, uint64_t n_units, const uint32_t* first_of,
                                       const uint8_t* keep_doc, const uint64_t* out_offsets, uint8_t* out_text,
-                                      uint64_t out_capacity) {
+                                      uint64_t out_capacity, const uint8_t* whole_doc) {
     REQUIRE(ctx, "mdd_para_compact_write: ctx is NULL");
     if (n_docs == 0) return MDD_OK;
     REQUIRE(offsets && unit_base && first_of && keep_doc && out_offsets && ((text && out_text) || text_bytes == 0),
@@ -429,7 +515,7 @@ extern "C" int mdd_para_compact_write(mdd_ctx* ctx, const uint8_t* text, uint64_
     HIP_TRY(hipSetDevice(ctx->device));
     if ((reinterpret_cast<uintptr_t>(text) & 3u) == 0)  // the usual case (device allocations are aligned): dword per lane
         hipLaunchKernelGGL(para_compact_write4_kernel, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
-                           n_docs, unit_base, n_units, first_of, keep_doc, out_offsets, out_text, out_capacity);
+                           n_docs, unit_base, n_units, first_of, keep_doc, out_offsets, out_text, out_capacity, whole_doc);
     else
         hipLaunchKernelGGL(para_compact_kernel<true>, dim3(wave_grid(ctx, n_docs)), dim3(256), 0, ctx->stream, text, text_bytes, offsets,
                            n_docs, unit_base, n_units, first_of, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr, keep_doc,

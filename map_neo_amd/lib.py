@@ -48,7 +48,8 @@ SIGNATURES = {
     "mdd_para_count": (_int, [_vp, _vp, _u64, _vp, _u64, _vp]),
     "mdd_para_units": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
     "mdd_para_compact_count": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp]),
-    "mdd_para_compact_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _u64]),
+    "mdd_para_compact_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _vp]),
+    "mdd_para_doc_sums": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mdd_substr_mark": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int, _int, _vp, _u64, _vp]),
     "mdd_substr_mark_sorted": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int, _int, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "mdd_substr_candidates": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "mdd_normalize_en_write": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _u64]),
     "mdd_gather_docs": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64]),
     "mdd_exact_group": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _vp, _vp]),
+    "mdd_exact_group_cps": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _u64, _int, _vp, _vp, _u64, _vp, _vp, _vp]),
     "mdd_jsonl_count_lines": (_int, [_vp, _vp, _u64, _vp, _vp]),
     "mdd_jsonl_line_begins": (_int, [_vp, _vp, _u64, _vp, _vp, _u64]),
     "mdd_jsonl_scan": (_int, [_vp, _vp, _u64, _vp, _u64, C.c_char_p, C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp]),

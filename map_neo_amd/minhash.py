@@ -96,6 +96,7 @@ class Engine:
         self.substr_method = os.environ.get("MDD_SUBSTR_METHOD", "auto")
         # sorted method: prove most windows unique first (mdd_substr_candidates); "0" sorts every window (A/B, tests)
         self.substr_filter = os.environ.get("MDD_SUBSTR_FILTER", "1") != "0"
+        self._exact_coll = 0
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -341,28 +342,45 @@ class Engine:
                    "mdd_removed_mask")
         return removed, cnt
 
+    @property
+    def last_exact_collisions(self) -> int:
+        """tag matches of the last exact_group call that were different bytes (read lazily: no synchronisation in the call)"""
+        c = self._exact_coll
+        return int(c.item()) if isinstance(c, torch.Tensor) else int(c)
+
+    @last_exact_collisions.setter
+    def last_exact_collisions(self, v):
+        self._exact_coll = v
+
     def exact_group(self, text: torch.Tensor, ubeg: torch.Tensor, uend: torch.Tensor, key_bits: int = 64,
-                    text_host: Optional[np.ndarray] = None) -> torch.Tensor:
+                    text_host: Optional[np.ndarray] = None, avg_unit_bytes: Optional[int] = None, want_cps: bool = False):
         """first_of[u] = smallest unit index with bytes identical to unit u (int32 tensor, u32 bits).  Exact: hash
         tag matches are confirmed on the bytes inside the kernels (`last_exact_collisions` counts the false ones).
-        `text_host` is accepted for compatibility and unused."""
+        `text_host` is accepted for compatibility and unused.  avg_unit_bytes: picks the hash kernel (computed from the
+        ranges, with a synchronisation, when not given).  want_cps: also return the units' code-point counts (int32)."""
         n = ubeg.numel()
         first_of = self.empty(n, torch.int32)
+        cps = self.empty(n, torch.int32) if want_cps else None
         self.last_exact_collisions = 0
         if n == 0:
-            return first_of
-        total = int((uend - ubeg).sum().item())
+            return (first_of, cps) if want_cps else first_of
+        if avg_unit_bytes is None:
+            avg_unit_bytes = max(0, int((uend - ubeg).sum().item())) // n
         tab_size = 2
         while tab_size < 2 * n:
             tab_size *= 2
         key = self.empty(n, torch.int64)
         table = self.empty(tab_size, torch.int64)
         cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
-        _lib.check(self.L.mdd_exact_group(self.ctx, _ptr(text), max(0, text.numel() - TEXT_PAD), _ptr(ubeg), _ptr(uend), n,
-                                          max(0, total) // n, key_bits, _ptr(key), _ptr(table), tab_size, _ptr(first_of),
-                                          _ptr(cnt)), "mdd_exact_group")
-        self.last_exact_collisions = int(cnt.item())
-        return first_of
+        tb = max(0, text.numel() - TEXT_PAD)
+        if want_cps:
+            _lib.check(self.L.mdd_exact_group_cps(self.ctx, _ptr(text), tb, _ptr(ubeg), _ptr(uend), n, avg_unit_bytes, key_bits, _ptr(key),
+                                                  _ptr(table), tab_size, _ptr(first_of), _ptr(cnt), _ptr(cps)), "mdd_exact_group_cps")
+        else:
+            _lib.check(self.L.mdd_exact_group(self.ctx, _ptr(text), tb, _ptr(ubeg), _ptr(uend), n, avg_unit_bytes, key_bits, _ptr(key),
+                                              _ptr(table), tab_size, _ptr(first_of), _ptr(cnt)), "mdd_exact_group")
+        self.last_exact_collisions = cnt
+        return (first_of, cps) if want_cps else first_of
 
     def paragraph_dedup(self, text: torch.Tensor, offsets: torch.Tensor, min_len: int = 20, key_bits: int = 64):
         """Paragraph dedup of a packed corpus (PAR:15-30), documents in (id, input) order.  Returns
@@ -381,14 +399,17 @@ class Engine:
         uend = self.empty(n_units, torch.int64)
         _lib.check(self.L.mdd_para_units(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(base), n_units, _ptr(ubeg),
                                          _ptr(uend)), "mdd_para_units")
-        first_of = self.exact_group(text, ubeg, uend, key_bits)
-        del ubeg, uend
+        # the grouping's hash pass counts the paragraphs' code points on the way, so the per-document sums come from the
+        # units (~28 bytes per paragraph) instead of another pass over the text
+        first_of, ucps = self.exact_group(text, ubeg, uend, key_bits, avg_unit_bytes=text_bytes // max(1, n_units), want_cps=True)
         kept_b = torch.zeros(n, dtype=torch.int64, device=self.device)
         kept_c = torch.zeros(n, dtype=torch.int64, device=self.device)
         has_unit = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        _lib.check(self.L.mdd_para_compact_count(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(base), n_units,
-                                                 _ptr(first_of), _ptr(kept_b), _ptr(kept_c), _ptr(has_unit)),
-                   "mdd_para_compact_count")
+        whole = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.mdd_para_doc_sums(self.ctx, _ptr(offsets), n, text_bytes, _ptr(base), n_units, _ptr(ubeg), _ptr(uend),
+                                            _ptr(ucps), _ptr(first_of), _ptr(kept_b), _ptr(kept_c), _ptr(has_unit), _ptr(whole)),
+                   "mdd_para_doc_sums")
+        del ubeg, uend, ucps
         keep_doc = has_unit != 0
         if min_len > 0:
             keep_doc &= kept_c >= min_len
@@ -398,7 +419,7 @@ class Engine:
         out_text = torch.zeros(padded_size(total), dtype=torch.uint8, device=self.device)
         keep_u8 = keep_doc.to(torch.uint8)
         _lib.check(self.L.mdd_para_compact_write(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, _ptr(base), n_units,
-                                                 _ptr(first_of), _ptr(keep_u8), _ptr(out_offs_all), _ptr(out_text), total),
+                                                 _ptr(first_of), _ptr(keep_u8), _ptr(out_offs_all), _ptr(out_text), total, _ptr(whole)),
                    "mdd_para_compact_write")
         docs = torch.nonzero(keep_doc).flatten()
         out_offs = torch.cat([out_offs_all[:-1][docs], out_offs_all[-1:]])

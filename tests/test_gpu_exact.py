@@ -473,3 +473,47 @@ def test_substr_resolved_anchors_clusters_with_edits_vs_oracle(sorted_method):
                 assert engine.last_substr_candidates is not None
         finally:
             engine.set_segment_bytes(0)
+
+
+def test_para_doc_sums_equal_the_text_pass(engine):
+    """mdd_para_doc_sums (per-document sums from the units + the code points mdd_exact_group_cps counts) ==
+    mdd_para_compact_count (the same sums from a pass over the text), on multi-byte text with empty paragraphs, empty
+    documents and repeated paragraphs; whole_doc marks exactly the documents whose output is the document itself"""
+    import ctypes as C
+    import torch
+    from map_neo_amd import lib as _lib
+    from map_neo_amd.minhash import TEXT_PAD
+    rng = np.random.Generator(np.random.PCG64(12))
+    docs = _corpus(rng, 500) + ["", "\n", "\n\n", "é\né\nü", "x" * 700 + "\n" + "数据" * 200]
+    buf, offs = pack_texts(docs)
+    text, o = engine.to_device(buf), engine.to_device(offs)
+    n, tb = len(docs), text.numel() - TEXT_PAD
+    p = lambda t: C.c_void_p(t.data_ptr()) if t.numel() else C.c_void_p(0)
+    per_doc = torch.zeros(n, dtype=torch.int64, device=engine.device)
+    _lib.check(engine.L.mdd_para_count(engine.ctx, p(text), tb, p(o), n, p(per_doc)))
+    base = torch.zeros(n + 1, dtype=torch.int64, device=engine.device)
+    torch.cumsum(per_doc, 0, out=base[1:])
+    nu = int(base[-1].item())
+    ubeg, uend = torch.zeros(nu, dtype=torch.int64, device=engine.device), torch.zeros(nu, dtype=torch.int64, device=engine.device)
+    _lib.check(engine.L.mdd_para_units(engine.ctx, p(text), tb, p(o), n, p(base), nu, p(ubeg), p(uend)))
+    for avg in (0, 1000):                                  # thread-per-unit and wave-per-unit hashing count alike
+        first_of, cps = engine.exact_group(text, ubeg, uend, avg_unit_bytes=avg, want_cps=True)
+        raw = buf.tobytes()
+        exp_cps = [len(raw[int(b):int(e)].decode("utf8")) for b, e in zip(ubeg.cpu().tolist(), uend.cpu().tolist())]
+        assert cps.cpu().tolist() == exp_cps
+    res = []
+    for which in ("text", "units"):
+        kb, kc = torch.zeros(n, dtype=torch.int64, device=engine.device), torch.zeros(n, dtype=torch.int64, device=engine.device)
+        hu, whole = torch.zeros(n, dtype=torch.uint8, device=engine.device), torch.zeros(n, dtype=torch.uint8, device=engine.device)
+        if which == "text":
+            _lib.check(engine.L.mdd_para_compact_count(engine.ctx, p(text), tb, p(o), n, p(base), nu, p(first_of), p(kb), p(kc), p(hu)))
+        else:
+            _lib.check(engine.L.mdd_para_doc_sums(engine.ctx, p(o), n, tb, p(base), nu, p(ubeg), p(uend), p(cps), p(first_of), p(kb), p(kc),
+                                                  p(hu), p(whole)))
+        res.append((kb.cpu(), kc.cpu(), hu.cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    fo = first_of.cpu().numpy().view(np.uint32)
+    bs = base.cpu().numpy()
+    exp_whole = [int(bs[d + 1] > bs[d] and all(fo[u] == u for u in range(bs[d], bs[d + 1]))) for d in range(n)]
+    assert whole.cpu().tolist() == exp_whole and 0 < sum(exp_whole) < n
