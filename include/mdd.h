@@ -119,19 +119,21 @@ int mdd_signatures_noalloc(mdd_ctx* ctx, const uint8_t* text, uint64_t text_byte
  * the context's stream hashes the documents while the text is still arriving: the call enqueues the chunked
  * host-to-device copies of text_host[0, text_bytes) into text_dev on `copy_stream` (a hipStream_t other than the
  * context's stream; created with hipStreamNonBlocking when the context runs on the default NULL stream, which would
- * otherwise synchronise with it implicitly -- the call checks), each followed by a stream-ordered host function
- * (hipLaunchHostFunc) that publishes the number of bytes that have landed in a pinned host word the kernel polls; a wave
+ * otherwise synchronise with it implicitly -- the call checks), back to back, with an event behind each chunk; behind
+ * that event, on a stream of the context's own, a host function (hipLaunchHostFunc) publishes the number of bytes that
+ * have landed in a pinned host word the kernel polls (round 3: on the copy stream itself the host functions kept the
+ * copy engine waiting for a host thread between any two chunks); `copy_stream` ends up behind the last of them.  A wave
  * starts a document only when every byte it can touch has landed.  Results are those of
  * mdd_signatures on the same text, bit for bit.
  *   text_host   HOST pointer, pinned (hipHostMalloc / hipHostRegister / torch pin_memory)
  *   text_dev    device buffer, 256-byte aligned, text_bytes + MDD_TEXT_PAD capacity; holds the text afterwards
  *   offsets     DEVICE, n_docs+1 (copy them first, on the context's stream)
- *   chunk_bytes copy granularity (0 = 32 MiB; a multiple of 256, >= 1 MiB)
+ *   chunk_bytes copy granularity (0 = 16 MiB; a multiple of 256, >= 1 MiB)
  * Asynchronous.  The kernel cannot wait forever: a wave that has waited 4 s for its text sets a status word and
  * every wave of that launch leaves; the verdict is sticky -- the next mdd_ctx_sync returns MDD_ERR_HIP (and clears it)
  * however many streamed calls were enqueued in between, and the signatures of all of them are then suspect.  The first
- * call on a context allocates a small pinned table and three events (set-up, all or nothing); later calls allocate
- * nothing. */
+ * call on a context allocates a small pinned table, a stream and three events (set-up, all or nothing), and a call
+ * creates one event per chunk the first time it needs it; after that calls allocate nothing. */
 int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* text_host, uint64_t text_bytes,
                              uint8_t* text_dev, const uint64_t* offsets, uint64_t n_docs, int unit, int width, int K,
                              const uint64_t* a, const uint64_t* b, uint32_t* sig_out, uint64_t chunk_bytes);

@@ -32,6 +32,10 @@ struct mdd_ctx {
     ReadyNote* notes;           // host: arguments of the stream-ordered host functions (2 * READY_SLOTS, alternating halves per call)
     hipEvent_t stream_ev[2];    // end of the copy-stream work of the call that last used each half
     hipEvent_t order_ev;        // orders the copy stream behind the compute stream at the start of a call
+    hipStream_t note_stream;    // the host functions that publish the byte counts run here, BEHIND the copy stream (an event per
+                                // chunk), not on it: a late host thread then delays a count, never the next copy
+    hipEvent_t* chunk_ev;       // 2 * READY_SLOTS events, created on first use (n_chunk_ev[half] of each half exist)
+    uint32_t n_chunk_ev[2];
     uint32_t stream_calls;      // calls so far (selects the half)
     bool stream_pending;        // a streamed call was enqueued since the last mdd_ctx_sync
     // multi-GPU exchange (mdd_comm.hip): RCCL communicator (ncclComm_t) + staging for the counts

@@ -1105,6 +1105,9 @@ int mdd_ctx_create(int device, void* hip_stream, mdd_ctx** out) {
     c->ready_flag_dev = nullptr;
     c->notes = nullptr;
     c->stream_ev[0] = c->stream_ev[1] = c->order_ev = nullptr;
+    c->note_stream = nullptr;
+    c->chunk_ev = nullptr;
+    c->n_chunk_ev[0] = c->n_chunk_ev[1] = 0;
     c->stream_calls = 0;
     c->stream_pending = false;
     // device address of this GPU's copy of `scratch` (set-up work: done here, never in mdd_signatures_noalloc)
@@ -1131,9 +1134,18 @@ int mdd_ctx_destroy(mdd_ctx* ctx) {
     (void)mdd_comm_destroy(ctx);
     if (ctx->seg_items) (void)hipFree(ctx->seg_items);
     if (ctx->ready_host) (void)hipHostFree(const_cast<uint64_t*>(ctx->ready_host));
+    if (ctx->note_stream) {
+        (void)hipStreamSynchronize(ctx->note_stream);  // its host functions read ctx->notes
+        (void)hipStreamDestroy(ctx->note_stream);
+    }
     delete[] ctx->notes;
     for (hipEvent_t e : {ctx->stream_ev[0], ctx->stream_ev[1], ctx->order_ev})
         if (e) (void)hipEventDestroy(e);
+    if (ctx->chunk_ev) {
+        for (uint32_t h = 0; h < 2; h++)
+            for (uint32_t i = 0; i < ctx->n_chunk_ev[h]; i++) (void)hipEventDestroy(ctx->chunk_ev[h * 4096 + i]);
+        delete[] ctx->chunk_ev;
+    }
     delete ctx;
     return MDD_OK;
 }
@@ -1282,7 +1294,9 @@ int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* tex
             "mdd_signatures_from_host: copy_stream must be a stream other than the context's");
     REQUIRE((text_host && text_dev) || text_bytes == 0, "mdd_signatures_from_host: NULL text");
     REQUIRE((reinterpret_cast<uintptr_t>(text_dev) & 255u) == 0, "mdd_signatures_from_host: text_dev must be 256-byte aligned");
-    if (chunk_bytes == 0) chunk_bytes = 32ull << 20;  // measured on C2: 8 MiB 71.8 ms, 16: 64.9, 32: 57.7, 64: 58.2, 128: 59.6 (resident 54.5)
+    // measured on C2 (resident 54.4 ms): 8 MiB 56.1 ms, 16: 56.1, 32: 56.5, 64: 57.0 -- the size only sets the kernel's head
+    // start now.  (With the host functions on the copy stream itself, round 2: 8 MiB 71.8 ms, 16: 64.9, 32: 57.7, 64: 58.2.)
+    if (chunk_bytes == 0) chunk_bytes = 16ull << 20;
     REQUIRE(chunk_bytes >= (1ull << 20) && chunk_bytes % 256 == 0, "mdd_signatures_from_host: chunk_bytes must be a multiple of 256 >= 1 MiB");
     constexpr uint64_t READY_SLOTS = 4096;
     REQUIRE(text_bytes / chunk_bytes + 16 <= READY_SLOTS, "mdd_signatures_from_host: more than %llu chunks; raise chunk_bytes",
@@ -1314,15 +1328,22 @@ int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* tex
         if (se == hipSuccess) se = hipHostGetDevicePointer(reinterpret_cast<void**>(&flag_dev), hp, 0);
         for (int i = 0; i < 3 && se == hipSuccess; i++) se = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
         ReadyNote* notes = se == hipSuccess ? new (std::nothrow) ReadyNote[2 * READY_SLOTS] : nullptr;
-        if (se != hipSuccess || !notes) {
+        hipEvent_t* cev = se == hipSuccess ? new (std::nothrow) hipEvent_t[2 * READY_SLOTS]() : nullptr;
+        hipStream_t ns = nullptr;
+        if (se == hipSuccess && notes && cev) se = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
+        if (se != hipSuccess || !notes || !cev) {
             for (hipEvent_t e : ev)
                 if (e) (void)hipEventDestroy(e);
             if (hp) (void)hipHostFree(hp);
+            delete[] notes;
+            delete[] cev;
             return fail(MDD_ERR_HIP, "mdd_signatures_from_host: set-up failed: %s", se != hipSuccess ? hipGetErrorString(se) : "out of host memory");
         }
         *static_cast<volatile uint64_t*>(hp) = 0;
         ctx->ready_flag_dev = flag_dev;
         ctx->notes = notes;
+        ctx->chunk_ev = cev;
+        ctx->note_stream = ns;
         ctx->stream_ev[0] = ev[0];
         ctx->stream_ev[1] = ev[1];
         ctx->order_ev = ev[2];
@@ -1340,9 +1361,12 @@ int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* tex
     HIP_TRY(hipMemsetAsync(ctx->stream_words + 3, 0, sizeof(uint64_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->order_ev, ctx->stream));
     HIP_TRY(hipStreamWaitEvent(cs, ctx->order_ev, 0));
-    // copy stream: a chunk, then a stream-ordered host function that publishes the byte count now valid (in pinned host
-    // memory, which the kernel can poll coherently; a count written into ordinary device memory by the copy engine is
-    // not visible to a running kernel).  The kernel is launched behind the FIRST chunk: a grid whose waves all sleep
+    // copy stream: the chunks, back to back, an event behind each.  Note stream: behind chunk k's event a host function that
+    // publishes the byte count now valid (in pinned host memory, which the kernel can poll coherently; a count written
+    // into ordinary device memory by the copy engine is not visible to a running kernel).  Round 2 had the host functions
+    // ON the copy stream: the copy engine then idled between two chunks until a host thread had been woken and had run
+    // the function -- ~70 wake-ups per pass, and a busy host made a pass 63 instead of 58 ms.  Now a
+    // late host function delays one count and nothing else.  The kernel is launched behind the FIRST chunk: a grid whose waves all sleep
     // while they wait for their first bytes was measured to put the device into a slower state for the whole launch
     // (kernel 62 instead of 54 ms, copies 44 instead of 37 ms); with one chunk of head start the copy engine (~57 GB/s)
     // stays ahead of the hashing (~40 GB/s) and waves wait only when the kernel is faster than PCIe.
@@ -1357,11 +1381,17 @@ int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* tex
         uint64_t n = text_bytes - done < chunk_bytes ? text_bytes - done : chunk_bytes;
         if (n) ce = hipMemcpyAsync(text_dev + done, text_host + done, n, hipMemcpyHostToDevice, cs);
         done += n;
+        if (ce == hipSuccess && k >= ctx->n_chunk_ev[half]) {
+            ce = hipEventCreateWithFlags(&ctx->chunk_ev[half * READY_SLOTS + k], hipEventDisableTiming);
+            if (ce == hipSuccess) ctx->n_chunk_ev[half] = k + 1;
+        }
+        if (ce == hipSuccess) ce = hipEventRecord(ctx->chunk_ev[half * READY_SLOTS + k], cs);
+        if (ce == hipSuccess) ce = hipStreamWaitEvent(ctx->note_stream, ctx->chunk_ev[half * READY_SLOTS + k], 0);
         if (ce == hipSuccess) {
             ReadyNote* nt = ctx->notes + half * READY_SLOTS + k;
             nt->flag = ctx->ready_host;
             nt->value = ctx->stream_base + done;
-            ce = hipLaunchHostFunc(cs, [](void* p) { ReadyNote* q = static_cast<ReadyNote*>(p); *q->flag = q->value; }, nt);
+            ce = hipLaunchHostFunc(ctx->note_stream, [](void* p) { ReadyNote* q = static_cast<ReadyNote*>(p); *q->flag = q->value; }, nt);
         }
         k++;
         if (!launched && ce == hipSuccess) {
@@ -1375,13 +1405,18 @@ int mdd_signatures_from_host(mdd_ctx* ctx, void* copy_stream, const uint8_t* tex
         }
     }
     ctx->stream_base += text_bytes;
-    (void)hipEventRecord(ctx->stream_ev[half], cs);
     if (rc != MDD_OK) ce = hipErrorUnknown;  // argument error found by the shared body: nothing was launched; fix the flag below
     if (ce != hipSuccess) {
         // make the flag reach this call's end anyway so that LATER calls start from a consistent base; this call's
         // kernel may then hash text that never arrived -- the error return tells the caller to discard its output
-        (void)hipLaunchHostFunc(cs, [](void* p) { ReadyNote* q = static_cast<ReadyNote*>(p); *q->flag = q->value; },
+        (void)hipLaunchHostFunc(ctx->note_stream, [](void* p) { ReadyNote* q = static_cast<ReadyNote*>(p); *q->flag = q->value; },
                                 &(ctx->notes[half * READY_SLOTS + READY_SLOTS - 1] = ReadyNote{ctx->ready_host, ctx->stream_base}));
+    }
+    // end of this half's work on the note stream (its notes and events are free again once this event has fired); the
+    // caller's copy stream waits for it too, so that "the copy stream is done" still means "the counts are published"
+    (void)hipEventRecord(ctx->stream_ev[half], ctx->note_stream);
+    (void)hipStreamWaitEvent(cs, ctx->stream_ev[half], 0);
+    if (ce != hipSuccess) {
         if (rc != MDD_OK) return rc;
         return fail(MDD_ERR_HIP, "mdd_signatures_from_host: copy failed: %s", hipGetErrorString(ce));
     }
