@@ -264,6 +264,34 @@ def cpus_of(cpulist: str):
     return out
 
 
+def bench_config_id(n_global: int, corpus_config: str = "auto") -> int:
+    return int(corpus_config) if corpus_config != "auto" else (2 if n_global < 50_000_000 else 4)
+
+
+def bench_spec(n_global: int, mean_bytes: int, config_id: int):
+    """The synthetic corpus of a run: ONE global spec (near-duplicates cross the ranks' shards), a function of the job's
+    total size only -- so tools/bench_expected.py can hash the same corpus on one GPU (profiles/r3_bench_expected.jsonl)
+    and a multi-GPU run can be held against that result (n_removed_matches_single_gpu)."""
+    from map_neo_amd import corpus
+    seed = 20240519 + config_id                   # config id (SURVEY.md 8(d))
+    if config_id == 4:      # C4 as SURVEY 8(d) describes it: 15 % near-copies in clusters of 2-50 (Zipf), edit-rate sweep, indels
+        return corpus.CorpusSpec(n_global, mean_bytes, seed=seed, lang="en", dup_frac=0.15, clusters="zipf50",
+                                 edit_rates=(0.01, 0.05, 0.1, 0.2), indel_rate=0.005)
+    return corpus.CorpusSpec(n_global, mean_bytes, seed=seed, lang="en")
+
+
+def expected_n_removed(n_global: int, mean_bytes: int, config_id: int):
+    """n_removed of the single-GPU path on the same global corpus, when tools/bench_expected.py has measured it"""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r3_bench_expected.jsonl")):
+            r = json.loads(line)
+            if (r["n_docs"], r["mean_bytes"], r["corpus_config"], r["K"], r["bands"], r["rows"]) == (n_global, mean_bytes, config_id, K, BANDS, ROWS):
+                return int(r["n_removed"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,8 +326,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.docs is None:
         args.docs = 1_000_000 if world == 1 else 12_500_000
-    config_id = int(args.corpus_config) if args.corpus_config != "auto" else (2 if args.docs * world < 50_000_000 else 4)
-    seed = 20240519 + config_id                   # config id
+    config_id = bench_config_id(args.docs * world, args.corpus_config)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -334,11 +361,7 @@ def main():
     n_local = args.docs
     n_global = n_local * world
     # one global corpus spec; each rank generates its contiguous shard (near-duplicates cross shards)
-    if config_id == 4:      # C4 as SURVEY 8(d) describes it: 15 % near-copies in clusters of 2-50 (Zipf), edit-rate sweep, indels
-        spec = corpus.CorpusSpec(n_global, args.mean_bytes, seed=seed, lang="en", dup_frac=0.15, clusters="zipf50",
-                                 edit_rates=(0.01, 0.05, 0.1, 0.2), indel_rate=0.005)
-    else:
-        spec = corpus.CorpusSpec(n_global, args.mean_bytes, seed=seed, lang="en")
+    spec = bench_spec(n_global, args.mean_bytes, config_id)
     d0 = rank * n_local
     t_gen = time.time()
     texts, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
@@ -572,6 +595,11 @@ def main():
             # cross-check that survives any path: the generator injected this many (near-)duplicates; a path that loses
             # band records or edges removes visibly fewer documents than that
             "n_injected_duplicates": int(spec.is_dup.sum()),
+            # the strongest check of the multi-GPU path that needs no second run: the SAME global corpus clustered on one GPU
+            # (tools/bench_expected.py -> profiles/r3_bench_expected.jsonl) must lose exactly as many documents
+            "n_removed_single_gpu_same_corpus": expected_n_removed(n_global, args.mean_bytes, config_id),
+            "n_removed_matches_single_gpu": (None if expected_n_removed(n_global, args.mean_bytes, config_id) is None
+                                             else expected_n_removed(n_global, args.mean_bytes, config_id) == n_removed),
             "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stages.items()},
             "corpus_gen_s": t_gen,
             "h2d_text_ms": h2d_ms,

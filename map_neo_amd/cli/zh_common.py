@@ -9,8 +9,10 @@ deduplication/minhash_lsh/*.py).  Artifact formats are the reference's:
 from __future__ import annotations
 
 import json
+import mmap
 import os
 import pickle
+import time
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -53,8 +55,8 @@ def iter_shards(files, field: str, workers: int):
 
 def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 256 << 20, line_index=None):
     """iter_shards with the field extraction on the device (hostio.read_jsonl_batch_device): the files are taken in
-    batches of about `batch_bytes`; threads only read a batch's files into ONE pinned host buffer (the next batch while
-    the GPU works on this one), the GPU finds the lines, validates and decodes them.  Yields per batch
+    batches of about `batch_bytes`; threads only read a batch's files into ONE pinned host buffer, the GPU finds the
+    lines, validates and decodes them; two batches are in flight on streams of their own.  Yields per batch
     (file indices int64 per document, line numbers uint64 per document, text DEVICE uint8 padded, offsets DEVICE int64
     [n+1], text_bytes).  gzip shards, batches with a lone "\\r" and unsuitable field names go through the host reader.
     line_index (a dict, optional) receives {file index: byte offsets of the file's line starts + its size} for the files
@@ -81,18 +83,54 @@ def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 
         return (np.full(len(line_no), k, dtype=np.int64), line_no, eng.to_device(buf), eng.to_device(np.ascontiguousarray(offs)),
                 int(text.size))
 
-    with ThreadPoolExecutor(workers) as rpool, ThreadPoolExecutor(1) as bpool:
-        read = lambda b: hostio.read_files_pinned([files[k] for k in b], rpool)      # noqa: E731
-        nxt = bpool.submit(read, batches[0]) if batches else None
-        for bi, b in enumerate(batches):
-            pre = nxt.result()
-            nxt = bpool.submit(read, batches[bi + 1]) if bi + 1 < len(batches) else None
-            r = hostio.read_jsonl_batch_device(eng, [files[k] for k in b], field, None, on_error="skip", pre=pre)
+    # Two producer threads, each with a stream and a context of its own, take the batches in turn: read (threads of
+    # rpool) -> H2D -> line index / scan / decode -> the host's share of the bookkeeping.  So batch i+1 crosses PCIe while
+    # batch i is being scanned, and the numpy work on one batch runs while the GPU has the other (ctypes calls, torch's
+    # synchronisations and numpy release the interpreter lock).  This thread takes the results in batch order, orders its
+    # own stream behind the producer's and hashes.
+    import threading
+
+    import torch
+
+    from ..minhash import Engine
+    tls = threading.local()
+    timing = os.environ.get("MDD_TIMING")
+
+    def produce(bi):
+        b = batches[bi]
+        if not hasattr(tls, "eng"):
+            tls.stream = torch.cuda.Stream(device=eng.device)
+            with torch.cuda.stream(tls.stream):
+                tls.eng = Engine(eng.device_index)
+        t0 = time.time()
+        with torch.cuda.stream(tls.stream):
+            pre = hostio.read_files_pinned([files[k] for k in b], rpool)
+            t1 = time.time()
+            r = hostio.read_jsonl_batch_device(tls.eng, [files[k] for k in b], field, None, on_error="skip", pre=pre)
             del pre
+            ev = torch.cuda.Event()
+            ev.record(tls.stream)
+        if timing:
+            print("[timing] batch %d (%d files): read %.1f ms, H2D + extract + bookkeeping %.1f ms, done at %.3f" %
+                  (bi, len(b), (t1 - t0) * 1e3, (time.time() - t1) * 1e3, time.time()), flush=True)
+        return r, ev
+
+    ahead = 2
+    with ThreadPoolExecutor(workers) as rpool, ThreadPoolExecutor(ahead) as bpool:
+        pending = [bpool.submit(produce, bi) for bi in range(min(ahead, len(batches)))]
+        for bi, b in enumerate(batches):
+            r, ev = pending[bi].result()
+            pending[bi] = None
+            if bi + ahead < len(batches):
+                pending.append(bpool.submit(produce, bi + ahead))
             if r is None:
                 for k in b:
                     yield host_route(k)
                 continue
+            here = torch.cuda.current_stream(eng.device)
+            here.wait_event(ev)
+            for t in (r["text"], r["offsets"]):          # allocated on the producer's stream, used on this one from here on
+                t.record_stream(here)
             for j in np.flatnonzero(r["n_bad"]).tolist():
                 print(f"procces file {os.path.basename(files[b[j]])}: {int(r['n_bad'][j])} lines skipped (not JSON objects)")
             if line_index is not None and r["line_starts"] is not None:
@@ -126,26 +164,43 @@ def copy_without_lines(src: str, dst: str, drop, line_starts=None) -> None:
     written as the runs between dropped lines: O(dropped lines) Python steps instead of one per line, so threads
     copying different files do not queue on the interpreter lock.
     line_starts (optional; from the device-side line index, only given for plain files without any "\\r"): byte offset of
-    every line start + the file size -- the runs are then copied inside the kernel (os.copy_file_range), the file's bytes
-    never enter this process."""
-    if line_starts is not None and hasattr(os, "copy_file_range"):
+    every line start + the file size -- the source is then mapped and the kept runs leave in ONE gathered write per 1024
+    runs (os.writev straight from the mapping: page cache to page cache, no Python-level copy, no call per run;
+    tools/zh5_write_probe.py: twice the rate of a copy_file_range per run, whose unaligned ranges go through a pipe)."""
+    if line_starts is not None and hasattr(os, "writev"):
         n_lines = len(line_starts) - 1
-        cuts = sorted(x for x in drop if 0 <= x < n_lines)
+        ls = np.asarray(line_starts, dtype=np.int64)
+        cuts = np.asarray(sorted(x for x in drop if 0 <= x < n_lines), dtype=np.int64)
+        lo = np.concatenate(([0], ls[cuts + 1]))              # kept runs [lo, hi): between dropped lines
+        hi = np.concatenate((ls[cuts], [ls[-1]]))
+        keep = hi > lo
+        fd = os.open(dst, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:
-            with open(src, "rb") as fi, open(dst, "wb") as fo:
-                pos = 0
-                for d in cuts + [None]:
-                    end = int(line_starts[d]) if d is not None else int(line_starts[-1])
-                    while pos < end:
-                        k = os.copy_file_range(fi.fileno(), fo.fileno(), end - pos, pos)
-                        if k <= 0:
-                            raise OSError("copy_file_range made no progress")
-                        pos += k
-                    if d is not None:
-                        pos = int(line_starts[d + 1])
-            return
-        except OSError:
-            pass                                    # file systems without it (EXDEV, ENOSYS): the byte route below
+            if int(ls[-1]) > 0 and keep.any():
+                with open(src, "rb") as fi:
+                    m = mmap.mmap(fi.fileno(), 0, prot=mmap.PROT_READ)
+                mv = memoryview(m)
+                try:
+                    iov = [mv[a:b] for a, b in zip(lo[keep].tolist(), hi[keep].tolist())]
+                    for i in range(0, len(iov), 1024):          # IOV_MAX
+                        chunk = iov[i:i + 1024]
+                        want, got = sum(len(x) for x in chunk), os.writev(fd, chunk)
+                        if got < want:                          # short write: the rest of the chunk piece by piece
+                            for x in chunk:
+                                if got >= len(x):
+                                    got -= len(x)
+                                    continue
+                                x = x[got:]
+                                got = 0
+                                while len(x):
+                                    x = x[os.write(fd, x):]
+                finally:
+                    iov = chunk = x = None
+                    mv.release()
+                    m.close()
+        finally:
+            os.close(fd)
+        return
     with open(src, "rb") as f:
         data = f.read()
     # The reference reads plain text only (ZH-1:40, ZH-5:9); the ingest of these commands also accepts gzip'd shards and

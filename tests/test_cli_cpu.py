@@ -97,6 +97,17 @@ def test_copy_without_lines_equals_line_loop(tmp_path):
             dst = tmp_path / "dst.jsonl"
             Z.copy_without_lines(str(src), str(dst), drop)
             assert dst.read_bytes() == exp, (data, drop)
+            # the byte-range route of the fused command: line starts as the device-side index gives them (+ the file size)
+            starts = [0] + [i + 1 for i, c in enumerate(data) if c == 10 and i + 1 < len(data)] + [len(data)] if data else [0]
+            Z.copy_without_lines(str(src), str(dst), drop, np.asarray(starts, dtype=np.int64))
+            assert dst.read_bytes() == exp, (data, drop, "line_starts")
+    # more kept runs than one gathered write takes (IOV_MAX = 1024)
+    data = b"".join(b"line %d\n" % i for i in range(5000))
+    src.write_bytes(data)
+    drop = set(range(0, 5000, 2))
+    starts = np.concatenate(([0], np.flatnonzero(np.frombuffer(data, dtype=np.uint8) == 10) + 1))
+    Z.copy_without_lines(str(src), str(dst), drop, starts)
+    assert dst.read_bytes() == b"".join(b"line %d\n" % i for i in range(1, 5000, 2))
 
 
 def test_shard_output_names_are_unique_and_keep_the_dotted_part():

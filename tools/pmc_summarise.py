@@ -37,7 +37,7 @@ scatter = {"fetch_bytes_counted_per_scattered_16B_load": cal_f.get("cal_read_sca
            "fetch_bytes_counted_by_the_1B_stores_per_request": cal_f.get("cal_write_scatter1", [0])[0] / N_REQ}
 # kernels whose reads are scattered single-line requests: the x2 of streaming reads does not apply to them
 SCATTERED = ("leaf_kernel", "bigleaf_kernel", "bucket_insert_kernel", "bucket_ids_kernel", "exact_insert_kernel", "exact_link_kernel",
-             "win_kernel", "uf_union_kernel", "uf_flatten_kernel")
+             "win_kernel", "uf_union_kernel", "uf_flatten_kernel", "anchor_resolve_kernel", "anchor_leaf_kernel")
 ff = fetch_factor["cal_read_dword"]
 bf = load(f"{src}/bench_FETCH_SIZE/bench_counter_collection.csv")
 bw = load(f"{src}/bench_WRITE_SIZE/bench_counter_collection.csv")
@@ -52,8 +52,22 @@ for k in bf:
         kern[k]["fetch_bytes_if_all_reads_scattered"] = bf[k][-1]
         kern[k]["fetch_correction_note"] = "x2 validated on streaming reads only; scattered 64-byte requests are counted at face value"
 bench_line = json.loads(open(f"{src}/bench_FETCH_SIZE.json").read().strip().splitlines()[-1])
+# the exact-substring stage as one figure (PMC total per pass): every kernel of the stage, last launch each
+SUBSTR = ("vmap_kernel", "anchor_kernel", "anchor_resolve_kernel", "anchor_leaf_kernel", "smear_kernel", "emit_kernel", "count2_kernel",
+          "scatter_kernel", "leaf_kernel", "bigleaf_kernel", "compact4_kernel", "compact_kernel", "scan_", "tile_map_kernel", "seg_plan_kernel")
+stage = {"fetch_bytes": 0.0, "write_bytes": 0.0, "kernels": []}
+for k, v in kern.items():
+    if k.split("<")[0].startswith(SUBSTR):
+        n_launch = 2 if k.split("<")[0] in ("scatter_kernel", "count2_kernel", "tile_map_kernel") else 1   # anchors + windows
+        for j in range(1, n_launch + 1):
+            if len(bf[k]) >= j:
+                stage["fetch_bytes"] += bf[k][-j] * (1.0 if k.split("<")[0] in SCATTERED else ff)
+                stage["write_bytes"] += (bw.get(k, [0] * j)[-j] if len(bw.get(k, [])) >= j else 0) * write_factor
+        stage["kernels"].append(k)
+stage["total_bytes"] = stage["fetch_bytes"] + stage["write_bytes"]
 summary = {"calibration": {"known_bytes": known, "fetch_correction": fetch_factor, "write_correction": write_factor, "scattered": scatter},
-           "workload": bench_line["config"], "kernels": kern}
+           "workload": bench_line["config"], "kernels": kern,
+           "exact_substr_stage_per_pass": stage}
 json.dump(summary, open(f"{dst}/summary.json", "w"), indent=1)
 for f in ("cal_FETCH_SIZE/cal_counter_collection.csv", "cal_WRITE_SIZE/cal_counter_collection.csv",
           "bench_FETCH_SIZE/bench_counter_collection.csv", "bench_WRITE_SIZE/bench_counter_collection.csv"):
@@ -66,3 +80,4 @@ for f in ("cal_FETCH_SIZE/cal_counter_collection.csv", "cal_WRITE_SIZE/cal_count
             r["Kernel_Name"] = r["Kernel_Name"][:120]
             w.writerow({k: r[k] for k in keep})
 print(json.dumps(summary["kernels"], indent=1))
+print(json.dumps(stage, indent=1))
