@@ -143,6 +143,8 @@ struct Sc {
         }
         return win[i - wbase];
     }
+    __device__ __forceinline__ uint32_t back(uint64_t i) { return at(i); }  // a byte behind the cursor (keys, the id's "null")
+    __device__ __forceinline__ bool line_ok() const { return true; }         // everything is checked where it is read
     __device__ __forceinline__ void ws() {
         while (p < end) {
             const uint32_t c = at(p);
@@ -228,7 +230,8 @@ __device__ bool sc_string(Sc& s, uint64_t* dec, bool* plain, bool* lone) {
     if (lone) *lone = ln;
     return true;
 }
-__device__ bool sc_number(Sc& s) {
+template <class S>
+__device__ bool sc_number(S& s) {
     auto dig = [&](uint64_t i) { return i < s.end && s.at(i) - '0' <= 9u; };
     if (s.p < s.end && s.at(s.p) == '-') s.p++;
     if (s.p >= s.end) return false;
@@ -249,7 +252,8 @@ __device__ bool sc_number(Sc& s) {
     }
     return true;
 }
-__device__ bool sc_literal(Sc& s, const char* w, uint32_t n) {
+template <class S>
+__device__ bool sc_literal(S& s, const char* w, uint32_t n) {
     if (s.end - s.p < n) return false;
     for (uint32_t i = 0; i < n; i++)
         if (s.at(s.p + i) != (uint32_t)(uint8_t)w[i]) return false;
@@ -257,7 +261,8 @@ __device__ bool sc_literal(Sc& s, const char* w, uint32_t n) {
     return true;
 }
 // skips any value (the host scanner recurses; here: a bit stack, 1 = inside an object, 0 = inside an array, 64 levels)
-__device__ bool sc_value(Sc& s) {
+template <class S>
+__device__ bool sc_value(S& s) {
     uint64_t stack = 0;
     int depth = 0;
     for (;;) {
@@ -336,6 +341,110 @@ struct ScanArgs {
 constexpr uint8_t ST_OK = 0, ST_NOCONTENT = 1, ST_FALLBACK = 2, ST_BLANK = 3;
 constexpr uint8_t ID_ABSENT = 0, ID_STRING = 1, ID_TOKEN = 2;  // as MDD_IO_ID_* (include/mdd_io.h)
 
+struct LineResult {
+    uint8_t status, idk;
+    uint64_t idb, ide, cpos, cdec;
+};
+
+// one line that is not blank, cursor at its first byte: the object's members, the content string, the id token
+template <class S>
+__device__ void scan_line(S& s, const ScanArgs& A, LineResult& R) {
+    uint8_t status = ST_FALLBACK, idk = ID_ABSENT;
+    uint64_t idb = 0, ide = 0, cpos = 0, cdec = 0;
+    bool have_content = false, content_ok = false, ok = true;
+    s.ws();
+    ok = s.p < s.end && s.at(s.p) == '{';
+    if (ok) {
+        s.p++;
+        s.ws();
+        if (s.p < s.end && s.at(s.p) == '}') {
+            s.p++;
+        } else {
+            for (;;) {
+                s.ws();
+                const uint64_t k0 = s.p + 1;
+                bool kplain = true;
+                if (!sc_string(s, nullptr, &kplain, nullptr) || !kplain) {  // escaped key: Python decides what it equals
+                    ok = false;
+                    break;
+                }
+                const uint64_t klen = s.p - 1 - k0;
+                s.ws();
+                if (s.p >= s.end || s.at(s.p) != ':') {
+                    ok = false;
+                    break;
+                }
+                s.p++;
+                s.ws();
+                bool is_c = klen == A.clen, is_i = A.ilen && klen == A.ilen;
+                for (uint32_t t = 0; is_c && t < A.clen; t++) is_c = s.back(k0 + t) == A.ckey[t];
+                for (uint32_t t = 0; is_i && t < A.ilen; t++) is_i = s.back(k0 + t) == A.ikey[t];
+                if (is_c) {  // duplicate keys: the last one wins, as in Python's dict
+                    have_content = true;
+                    content_ok = false;
+                    if (s.p < s.end && s.at(s.p) == '"') {
+                        bool lone = false;
+                        cpos = s.p;
+                        if (!sc_string(s, &cdec, nullptr, &lone)) {
+                            ok = false;
+                            break;
+                        }
+                        content_ok = !lone;
+                    } else if (!sc_value(s)) {
+                        ok = false;
+                        break;
+                    }
+                } else if (is_i) {
+                    const uint64_t v0 = s.p;
+                    if (s.p < s.end && s.at(s.p) == '"') {
+                        bool plain = true;
+                        if (!sc_string(s, nullptr, &plain, nullptr)) {
+                            ok = false;
+                            break;
+                        }
+                        if (plain) idk = ID_STRING, idb = v0 + 1, ide = s.p - 1;
+                        else idk = ID_TOKEN, idb = v0, ide = s.p;
+                    } else {
+                        if (!sc_value(s)) {
+                            ok = false;
+                            break;
+                        }
+                        idk = ID_TOKEN, idb = v0, ide = s.p;
+                        if (ide - idb == 4 && s.back(v0) == 'n' && s.back(v0 + 1) == 'u' && s.back(v0 + 2) == 'l' && s.back(v0 + 3) == 'l')
+                            idk = ID_ABSENT;  // row.get() is None
+                    }
+                } else if (!sc_value(s)) {
+                    ok = false;
+                    break;
+                }
+                s.ws();
+                if (s.p < s.end && s.at(s.p) == ',') {
+                    s.p++;
+                    continue;
+                }
+                if (s.p < s.end && s.at(s.p) == '}') {
+                    s.p++;
+                    break;
+                }
+                ok = false;
+                break;
+            }
+        }
+    }
+    if (ok) {
+        s.ws();
+        ok = s.p == s.end;  // json.loads raises on trailing data
+    }
+    if (ok) ok = s.line_ok();  // (wave scanner: utf-8 and escapes are checked chunk by chunk, over the whole line)
+    if (ok) status = (have_content && content_ok) ? ST_OK : ST_NOCONTENT;
+    if (status == ST_FALLBACK) idk = ID_ABSENT, idb = ide = 0;
+    R.status = status, R.idk = idk, R.idb = idb, R.ide = ide;
+    R.cpos = status == ST_OK ? cpos : 0;
+    R.cdec = status == ST_OK ? cdec : 0;
+}
+
+__device__ __forceinline__ bool py_blank(uint32_t c) { return c == ' ' || (c - 9u <= 4u) || (c - 0x1Cu <= 3u); }  // str.strip's ASCII whitespace
+
 __global__ void __launch_bounds__(256) jsonl_scan_kernel(ScanArgs A) {
     __shared__ __attribute__((aligned(4))) uint8_t lds_win[256 * WIN_STRIDE];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,114 +453,22 @@ __global__ void __launch_bounds__(256) jsonl_scan_kernel(ScanArgs A) {
     end = end < A.raw_bytes ? end : A.raw_bytes;
     beg = beg < end ? beg : end;
     if (end > beg && A.raw[end - 1] == 10u) end--;  // the line without its "\n"
-    uint8_t status = ST_FALLBACK, idk = ID_ABSENT;
-    uint64_t idb = 0, ide = 0, cpos = 0, cdec = 0;
     Sc s{A.raw, beg, end, lds_win + threadIdx.x * WIN_STRIDE, 1ull << 63};
     bool blank = true;
-    for (uint64_t q = beg; q < end; q++) {
-        const uint32_t c = s.at(q);
-        if (!(c == ' ' || (c - 9u <= 4u) || (c - 0x1Cu <= 3u))) {  // Python's ASCII whitespace (str.strip)
+    for (uint64_t q = beg; q < end; q++)
+        if (!py_blank(s.at(q))) {
             blank = false;
             break;
         }
-    }
-    if (blank) {
-        status = ST_BLANK;
-    } else {
-        bool have_content = false, content_ok = false, ok = true;
-        s.ws();
-        ok = s.p < s.end && s.at(s.p) == '{';
-        if (ok) {
-            s.p++;
-            s.ws();
-            if (s.p < s.end && s.at(s.p) == '}') {
-                s.p++;
-            } else {
-                for (;;) {
-                    s.ws();
-                    const uint64_t k0 = s.p + 1;
-                    bool kplain = true;
-                    if (!sc_string(s, nullptr, &kplain, nullptr) || !kplain) {  // escaped key: Python decides what it equals
-                        ok = false;
-                        break;
-                    }
-                    const uint64_t klen = s.p - 1 - k0;
-                    s.ws();
-                    if (s.p >= s.end || s.at(s.p) != ':') {
-                        ok = false;
-                        break;
-                    }
-                    s.p++;
-                    s.ws();
-                    bool is_c = klen == A.clen, is_i = A.ilen && klen == A.ilen;
-                    for (uint32_t t = 0; is_c && t < A.clen; t++) is_c = s.at(k0 + t) == A.ckey[t];
-                    for (uint32_t t = 0; is_i && t < A.ilen; t++) is_i = s.at(k0 + t) == A.ikey[t];
-                    if (is_c) {  // duplicate keys: the last one wins, as in Python's dict
-                        have_content = true;
-                        content_ok = false;
-                        if (s.p < s.end && s.at(s.p) == '"') {
-                            bool lone = false;
-                            cpos = s.p;
-                            if (!sc_string(s, &cdec, nullptr, &lone)) {
-                                ok = false;
-                                break;
-                            }
-                            content_ok = !lone;
-                        } else if (!sc_value(s)) {
-                            ok = false;
-                            break;
-                        }
-                    } else if (is_i) {
-                        const uint64_t v0 = s.p;
-                        if (s.p < s.end && s.at(s.p) == '"') {
-                            bool plain = true;
-                            if (!sc_string(s, nullptr, &plain, nullptr)) {
-                                ok = false;
-                                break;
-                            }
-                            if (plain) idk = ID_STRING, idb = v0 + 1, ide = s.p - 1;
-                            else idk = ID_TOKEN, idb = v0, ide = s.p;
-                        } else {
-                            if (!sc_value(s)) {
-                                ok = false;
-                                break;
-                            }
-                            idk = ID_TOKEN, idb = v0, ide = s.p;
-                            if (ide - idb == 4 && s.at(v0) == 'n' && s.at(v0 + 1) == 'u' && s.at(v0 + 2) == 'l' && s.at(v0 + 3) == 'l')
-                                idk = ID_ABSENT;  // row.get() is None
-                        }
-                    } else if (!sc_value(s)) {
-                        ok = false;
-                        break;
-                    }
-                    s.ws();
-                    if (s.p < s.end && s.at(s.p) == ',') {
-                        s.p++;
-                        continue;
-                    }
-                    if (s.p < s.end && s.at(s.p) == '}') {
-                        s.p++;
-                        break;
-                    }
-                    ok = false;
-                    break;
-                }
-            }
-        }
-        if (ok) {
-            s.ws();
-            ok = s.p == s.end;  // json.loads raises on trailing data
-        }
-        if (ok) status = (have_content && content_ok) ? ST_OK : ST_NOCONTENT;
-        if (status == ST_FALLBACK) idk = ID_ABSENT, idb = ide = 0;
-    }
-    A.status[i] = status;
-    A.content_pos[i] = status == ST_OK ? cpos : 0;
-    A.content_len[i] = status == ST_OK ? cdec : 0;
+    LineResult R{ST_BLANK, ID_ABSENT, 0, 0, 0, 0};
+    if (!blank) scan_line(s, A, R);
+    A.status[i] = R.status;
+    A.content_pos[i] = R.cpos;
+    A.content_len[i] = R.cdec;
     if (A.id_kind) {
-        A.id_kind[i] = idk;
-        A.id_beg[i] = idb;
-        A.id_end[i] = ide;
+        A.id_kind[i] = R.idk;
+        A.id_beg[i] = R.idb;
+        A.id_end[i] = R.ide;
     }
 }
 
