@@ -12,13 +12,15 @@
 //   line index   newline positions (SWAR test per dword, ballots for ranks): count per 16 KiB tile, caller's prefix sum,
 //                then line_begin[]; lone "\r" bytes are counted (text-mode readers end a line there: the caller sends such
 //                a shard to the host reader)
-//   scan         ONE THREAD PER LINE walks its line with the host scanner's state machine (iterative, 64-level bit stack):
-//                status, position of the content string, its decoded length, the id token.  Lines are independent and
-//                there are ~10^5..10^6 of them per shard, so the latency of the byte-wise walk hides behind occupancy.
+//   scan         ONE WAVE PER LINE runs the host scanner's grammar as an automaton over 64-byte chunks (string bodies, digit
+//                runs and whitespace are crossed with ballots; jsonl_scan_wave_kernel): status, position of the content
+//                string, its decoded length, the id token.  The first implementation, one THREAD per line walking the
+//                bytes (jsonl_scan_kernel), is kept as the independent one the tests compare with (MDD_JSONL_SCAN=thread).
 //   decode       ONE WAVE PER LINE copies / unescapes the content string into the packed text mdd_signatures consumes:
 //                a lane per byte, escape starts from the parity of backslash runs (ballot + count-leading-ones, carried
 //                across 64-byte chunks), \uXXXX and surrogate pairs decoded by the starting lane, output positions from
 //                ballots over the lanes' byte counts.  Chunks without a backslash are a straight coalesced copy.
+#include <cstdlib>
 #include <cstring>
 
 #include "mdd_common.h"
@@ -472,6 +474,398 @@ __global__ void __launch_bounds__(256) jsonl_scan_kernel(ScanArgs A) {
     }
 }
 
+// ---- scan, one WAVE per line ------------------------------------------------------------------------------------------------
+// A thread per line walks its ~2 KB byte by byte -- a dependent chain of LDS loads and branches -- while 63 other lines of the
+// wave wait for the longest of them: 80 % of the extraction's time.  Here the line's bytes sit in the lanes, 64 at a time, and
+// what is per-byte work inside a string body happens once per chunk with ballots:
+//   * escape starts from the parity of backslash runs (carried across chunks), the bytes each escape consumes, the closing
+//     quote = the first quote that is neither;
+//   * per lane: the escape's validity (\" \\ \/ \b \f \n \r \t \uXXXX), its decoded utf-8 length, surrogate pairs (a high half
+//     directly followed by a low one is ONE code point of 4 bytes; any other half is "lone": the value cannot be encoded);
+//   * utf-8: every lead byte checks its own continuation bytes (its dword holds them) and the line's continuation bytes are
+//     balanced against what its leads ask for -- so no byte >= 0x80 passes that Python's decoder would reject;
+//   * control characters, whitespace and digit runs.
+// The grammar is the thread scanner's (scan_line / sc_value / sc_number / sc_literal), written as an explicit automaton so
+// that the chunk is loaded at ONE place in the code (a cursor that fetches the next chunk wherever it is advanced compiled
+// to 200 KB of code and 248 VGPRs); every value the wave branches on is the same in all lanes.  utf-8 and escape checks
+// apply to the WHOLE line here -- outside strings such bytes are no JSON anyway -- which can only turn a line into a fallback.
+enum : uint32_t {
+    W_START,     // whitespace, then the line's '{'
+    W_OPEN_OBJ,  // after '{': whitespace, then '}' (an empty container is a complete value) or the first key
+    W_OPEN_ARR,  // after '[': whitespace, then ']' or the first element
+    W_KEY,       // whitespace, then the '"' of a key
+    W_COLON,     // whitespace, then ':'
+    W_VALUE,     // whitespace, then the first byte of a value
+    W_AFTER,     // a value has ended: whitespace, then ',' or the closer of the innermost container
+    W_END,       // the object is closed: only whitespace may follow
+    W_STRING,    // inside a string body (the states from here on take no whitespace)
+    W_NUM_MINUS,
+    W_NUM_ZERO,
+    W_NUM_INT,
+    W_NUM_FRAC0,
+    W_NUM_FRAC,
+    W_NUM_EXP0,
+    W_NUM_EXP1,
+    W_NUM_EXP,
+    W_LITERAL,   // the rest of true / false / null
+    W_FAIL
+};
+enum : uint32_t { P_KEY_NESTED, P_KEY_TOP, P_CONTENT, P_ID, P_OTHER };  // what the string being crossed is
+enum : uint32_t { K_NONE, K_CONTENT, K_ID };                            // which member of the line's object the next value belongs to
+
+__device__ __forceinline__ bool hex4v(const uint8_t* __restrict__ r, uint64_t q, uint32_t& cp) {
+    const int h0 = hexv(r[q]), h1 = hexv(r[q + 1]), h2 = hexv(r[q + 2]), h3 = hexv(r[q + 3]);
+    cp = (uint32_t)((h0 & 15) << 12 | (h1 & 15) << 8 | (h2 & 15) << 4 | (h3 & 15));
+    return (h0 | h1 | h2 | h3) >= 0;
+}
+
+// one wave per line, persistent: wave w takes lines w, w + #waves, ...
+__global__ void __launch_bounds__(256) jsonl_scan_wave_kernel(ScanArgs A) {
+    const uint32_t lane = lane_id();
+    const uint8_t* __restrict__ b = A.raw;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t w0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    for (uint64_t i = w0; i < A.n_lines; i += nw) {
+        uint64_t beg = A.line_begin[i], end = A.line_begin[i + 1];
+        end = end < A.raw_bytes ? end : A.raw_bytes;
+        beg = beg < end ? beg : end;
+        if (end > beg && b[end - 1] == 10u) end--;  // the line without its "\n"
+        bool blank = true;
+        for (uint64_t q0 = beg; q0 < end; q0 += 64) {
+            const uint64_t q = q0 + lane;
+            const uint32_t x = q < end ? b[q] : (uint32_t)' ';
+            if (__ballot(!py_blank(x))) {
+                blank = false;
+                break;
+            }
+        }
+        uint8_t status = ST_BLANK, idk = ID_ABSENT;
+        uint64_t idb = 0, ide = 0, cpos = 0, cdec = 0;
+        if (!blank) {
+            // ---- the chunk in the lanes and its masks
+            uint64_t p = beg, base = beg;
+            bool loaded = false;
+            uint32_t c = ' ';
+            uint64_t Q = 0, S = 0, CTRL = 0, NWS = 0, LONE = 0, C0 = 0, C1 = 0, C2 = 0, DIG = 0;
+            uint64_t carry_s = 0, prev_S = 0, prev_SU = 0;  // previous chunk: its last byte starts an escape; its escape starts; its \u starts
+            uint64_t need = 0, conts = 0;                   // continuation bytes the line's leads ask for / continuation bytes seen
+            bool bad = false;                               // an invalid escape or utf-8 sequence somewhere in the line
+            // ---- the automaton
+            uint32_t state = W_START, purpose = P_OTHER, pend = K_NONE, depth = 0, lit_left = 0;
+            uint64_t stack = 0, lit = 0;  // stack: the containers INSIDE the line's object, 1 = object (64 levels); lit: bytes still to match
+            uint64_t str_start = 0, str_n = 0, id_v0 = 0;
+            bool str_plain = true, str_lone = false, id_open = false, have_content = false, content_ok = false;
+#define VALUE_DONE(pos)                                                                          \
+    do {                                                                                         \
+        if (depth == 1u) {                                                                       \
+            if (id_open) {                                                                       \
+                idk = ID_TOKEN, idb = id_v0, ide = (pos), id_open = false;                       \
+                if (ide - idb == 4 && b[idb] == 'n' && b[idb + 1] == 'u' && b[idb + 2] == 'l' && b[idb + 3] == 'l') \
+                    idk = ID_ABSENT; /* row.get() is None */                                     \
+            }                                                                                    \
+            pend = K_NONE;                                                                       \
+        }                                                                                        \
+        state = W_AFTER;                                                                         \
+    } while (0)
+            for (;;) {
+                if (state == W_FAIL || p >= end) break;
+                if (!loaded || p - base >= 64) {
+                    base = loaded ? base + 64 : beg;
+                    loaded = true;
+                    const uint64_t q = base + lane;
+                    const bool in = q < end;
+                    // the lane's byte and the three behind it (bytes past `end` are the next line's or the buffer's padding:
+                    // every use below checks positions against `end`)
+                    const uint32_t w = in ? *reinterpret_cast<const mdd_u32_a1*>(b + q) : 0x20202020u;
+                    c = w & 0xFFu;
+                    const uint32_t c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu, c3 = w >> 24;
+                    bool badlane = false;
+                    uint32_t cnt = 1;
+                    if (__ballot(c >= 0x80u)) {
+                        uint32_t k = 0;
+                        if (c >= 0xC0u) {
+                            k = (c >= 0xC2u && c <= 0xDFu) ? 1u : (c >= 0xE0u && c <= 0xEFu) ? 2u : (c >= 0xF0u && c <= 0xF4u) ? 3u : 0u;
+                            bool ok = k != 0u && q + k < end && (c1 & 0xC0u) == 0x80u && (k < 2u || (c2 & 0xC0u) == 0x80u) &&
+                                      (k < 3u || (c3 & 0xC0u) == 0x80u);
+                            ok = ok && !((c == 0xE0u && c1 < 0xA0u) || (c == 0xEDu && c1 >= 0xA0u) || (c == 0xF0u && c1 < 0x90u) ||
+                                         (c == 0xF4u && c1 >= 0x90u));
+                            badlane = !ok;
+                        }
+                        conts += __builtin_popcountll(__ballot((c & 0xC0u) == 0x80u));
+                        need += __builtin_popcountll(__ballot(k & 1u)) + 2 * __builtin_popcountll(__ballot(k & 2u));
+                    }
+                    const uint64_t B = __ballot(c == '\\');
+                    uint64_t body = 0, SU = 0;
+                    S = 0, LONE = 0;
+                    if (B || carry_s || prev_SU) {
+                        // escape starts: a backslash with an even number of backslashes directly before it in its run
+                        bool st = false;
+                        if (c == '\\') {
+                            uint32_t r = 0;
+                            if (lane) {
+                                const uint64_t x = B << (64 - lane);  // the lanes below, aligned to the top
+                                r = (uint32_t)__builtin_clzll(~x);     // consecutive backslashes directly below (64 when x is all ones)
+                                if (r > lane) r = lane;
+                            }
+                            st = ((r + ((r == lane && carry_s) ? 1u : 0u)) & 1u) == 0u;
+                        }
+                        S = __ballot(st);
+                        const uint32_t e = (st && q + 1 < end) ? c1 : 0u;
+                        SU = __ballot(st && e == 'u');
+                        body = (S << 1) | carry_s | (SU << 2) | (SU << 3) | (SU << 4) | (SU << 5) | (prev_SU >> 62) | (prev_SU >> 61) |
+                               (prev_SU >> 60) | (prev_SU >> 59);
+                        bool lonelane = false;
+                        if (st) {
+                            if (e == 'u') {
+                                uint32_t cp = 0;
+                                if (q + 5 < end && hex4v(b, q + 2, cp)) {
+                                    if (cp - 0xD800u <= 0x3FFu) {
+                                        // a high half pairs with a low half that follows directly (Python's decoder); a following
+                                        // \u with bad digits is flagged by its own lane
+                                        uint32_t lo = 0;
+                                        const bool paired = q + 11 < end && b[q + 6] == '\\' && b[q + 7] == 'u' && hex4v(b, q + 8, lo) &&
+                                                            lo - 0xDC00u <= 0x3FFu;
+                                        if (paired) cnt = 4;
+                                        else lonelane = true;
+                                    } else if (cp - 0xDC00u <= 0x3FFu) {
+                                        // a low half belongs to the escape 6 bytes before it when that one is a high half
+                                        bool paired = false;
+                                        if (q >= beg + 6 && b[q - 6] == '\\' && b[q - 5] == 'u') {
+                                            uint32_t hi = 0;
+                                            const bool st6 = lane >= 6 ? (((S >> (lane - 6)) & 1u) != 0) : (((prev_S >> (lane + 58)) & 1u) != 0);
+                                            paired = st6 && hex4v(b, q - 4, hi) && hi - 0xD800u <= 0x3FFu;
+                                        }
+                                        if (paired) cnt = 0;
+                                        else lonelane = true;
+                                    } else {
+                                        cnt = cp < 0x80u ? 1u : (cp < 0x800u ? 2u : 3u);
+                                    }
+                                } else {
+                                    badlane = true;
+                                }
+                            } else if (!(e == '"' || e == '\\' || e == '/' || e == 'b' || e == 'f' || e == 'n' || e == 'r' || e == 't')) {
+                                badlane = true;  // includes a backslash that is the line's last byte (e = 0)
+                            }
+                        } else if ((body >> lane) & 1u) {
+                            cnt = 0;
+                        }
+                        LONE = __ballot(lonelane);
+                    }
+                    if (__ballot(badlane)) bad = true;
+                    C0 = __ballot(cnt & 1u), C1 = __ballot(cnt & 2u), C2 = __ballot(cnt & 4u);
+                    Q = __ballot(c == '"') & ~body;
+                    CTRL = __ballot(in && c < 0x20u);
+                    NWS = __ballot(!(c == ' ' || c == '\t' || c == '\n' || c == '\r'));
+                    DIG = __ballot(c - '0' <= 9u);
+                    carry_s = S >> 63;
+                    prev_S = S;
+                    prev_SU = SU;
+                    continue;
+                }
+                uint64_t ge = ~0ull << (uint32_t)(p - base);
+                if (state <= W_END) {  // the states that begin with whitespace
+                    const uint64_t m = NWS & ge;
+                    if (!m) {
+                        p = base + 64;
+                        continue;
+                    }
+                    p = base + (uint64_t)__builtin_ctzll(m);  // (< end: the lanes at and beyond `end` hold spaces)
+                    ge = ~0ull << (uint32_t)(p - base);
+                }
+                const uint32_t ch = (uint32_t)__builtin_amdgcn_readlane((int)c, __builtin_amdgcn_readfirstlane((int)(uint32_t)(p - base)));
+                const bool in_obj = depth == 1u || (stack & 1u);
+                switch (state) {
+                    case W_START:
+                        if (ch == '{') p++, state = W_OPEN_OBJ;
+                        else state = W_FAIL;
+                        break;
+                    case W_OPEN_OBJ:
+                        if (ch == '}') {
+                            p++;
+                            if (depth == 0u) state = W_END;  // the line is "{}"
+                            else VALUE_DONE(p);
+                        } else if (depth >= 65u) {
+                            state = W_FAIL;  // deeper than the host scanner follows
+                        } else {
+                            if (depth) stack = (stack << 1) | 1u;
+                            depth++;
+                            state = W_KEY;
+                        }
+                        break;
+                    case W_OPEN_ARR:
+                        if (ch == ']') {
+                            p++;
+                            VALUE_DONE(p);
+                        } else if (depth >= 65u) {
+                            state = W_FAIL;
+                        } else {
+                            stack = stack << 1;
+                            depth++;
+                            state = W_VALUE;
+                        }
+                        break;
+                    case W_KEY:
+                        if (ch == '"') {
+                            str_start = p, str_n = 0, str_plain = true, str_lone = false;
+                            purpose = depth == 1u ? P_KEY_TOP : P_KEY_NESTED;
+                            p++, state = W_STRING;
+                        } else {
+                            state = W_FAIL;
+                        }
+                        break;
+                    case W_COLON:
+                        if (ch == ':') p++, state = W_VALUE;
+                        else state = W_FAIL;
+                        break;
+                    case W_VALUE: {
+                        const bool top = depth == 1u;
+                        if (top && pend == K_CONTENT) have_content = true, content_ok = false;  // duplicate keys: the last one wins
+                        if (ch == '"') {
+                            str_start = p, str_n = 0, str_plain = true, str_lone = false;
+                            purpose = !top ? P_OTHER : pend == K_CONTENT ? P_CONTENT : pend == K_ID ? P_ID : P_OTHER;
+                            p++, state = W_STRING;
+                            break;
+                        }
+                        if (top && pend == K_ID) id_v0 = p, id_open = true;
+                        if (ch == '{') p++, state = W_OPEN_OBJ;
+                        else if (ch == '[') p++, state = W_OPEN_ARR;
+                        else if (ch == 't') p++, state = W_LITERAL, lit = 0x657572ull, lit_left = 3;      // "rue"
+                        else if (ch == 'f') p++, state = W_LITERAL, lit = 0x65736C61ull, lit_left = 4;    // "alse"
+                        else if (ch == 'n') p++, state = W_LITERAL, lit = 0x6C6C75ull, lit_left = 3;      // "ull"
+                        else if (ch == '-') p++, state = W_NUM_MINUS;
+                        else if (ch == '0') p++, state = W_NUM_ZERO;
+                        else if (ch - '1' <= 8u) p++, state = W_NUM_INT;
+                        else state = W_FAIL;  // includes NaN / Infinity, which Python accepts: the host decides
+                        break;
+                    }
+                    case W_AFTER:
+                        if (ch == ',') {
+                            p++, state = in_obj ? W_KEY : W_VALUE;
+                        } else if (ch == (in_obj ? (uint32_t)'}' : (uint32_t)']')) {
+                            p++;
+                            if (depth == 1u) {
+                                depth = 0, state = W_END;
+                            } else {
+                                stack >>= 1, depth--;
+                                VALUE_DONE(p);
+                            }
+                        } else {
+                            state = W_FAIL;
+                        }
+                        break;
+                    case W_END:
+                        state = W_FAIL;  // json.loads raises on trailing data
+                        break;
+                    case W_STRING: {
+                        const uint64_t m = Q & ge;
+                        const uint32_t stop = m ? (uint32_t)__builtin_ctzll(m) : 64u;
+                        const uint64_t region = stop < 64u ? (ge & ((1ull << stop) - 1ull)) : ge;  // the body's bytes in this chunk
+                        if (CTRL & region) {  // Python's json (strict) rejects raw control characters
+                            state = W_FAIL;
+                            break;
+                        }
+                        str_n += __builtin_popcountll(C0 & region) + 2 * __builtin_popcountll(C1 & region) + 4 * __builtin_popcountll(C2 & region);
+                        if (S & region) str_plain = false;
+                        if (LONE & region) str_lone = true;
+                        if (!m) {
+                            p = base + 64;
+                            break;
+                        }
+                        const uint64_t close = base + stop;
+                        p = close + 1;
+                        if (purpose == P_KEY_NESTED) {
+                            state = W_COLON;
+                        } else if (purpose == P_KEY_TOP) {
+                            if (!str_plain) {  // escaped key: Python decides what it equals
+                                state = W_FAIL;
+                                break;
+                            }
+                            const uint64_t k0 = str_start + 1, klen = close - k0;
+                            bool is_c = klen == A.clen, is_i = A.ilen && klen == A.ilen;
+                            for (uint32_t t = 0; is_c && t < A.clen; t++) is_c = b[k0 + t] == A.ckey[t];
+                            for (uint32_t t = 0; is_i && t < A.ilen; t++) is_i = b[k0 + t] == A.ikey[t];
+                            pend = is_c ? K_CONTENT : is_i ? K_ID : K_NONE;
+                            state = W_COLON;
+                        } else {
+                            if (purpose == P_CONTENT) {
+                                cpos = str_start, cdec = str_n, content_ok = !str_lone;
+                            } else if (purpose == P_ID) {
+                                if (str_plain) idk = ID_STRING, idb = str_start + 1, ide = close;
+                                else idk = ID_TOKEN, idb = str_start, ide = p;
+                            }
+                            VALUE_DONE(p);
+                        }
+                        break;
+                    }
+                    case W_NUM_MINUS:
+                        if (ch == '0') p++, state = W_NUM_ZERO;
+                        else if (ch - '1' <= 8u) p++, state = W_NUM_INT;
+                        else state = W_FAIL;
+                        break;
+                    case W_NUM_ZERO:
+                        if (ch == '.') p++, state = W_NUM_FRAC0;
+                        else if (ch == 'e' || ch == 'E') p++, state = W_NUM_EXP0;
+                        else VALUE_DONE(p);
+                        break;
+                    case W_NUM_INT:
+                    case W_NUM_FRAC:
+                    case W_NUM_EXP:
+                        if (ch - '0' <= 9u) {  // the rest of the digit run in this chunk
+                            const uint64_t m = ~DIG & ge;
+                            p = m ? base + (uint64_t)__builtin_ctzll(m) : base + 64;
+                        } else if (ch == '.' && state == W_NUM_INT) {
+                            p++, state = W_NUM_FRAC0;
+                        } else if ((ch == 'e' || ch == 'E') && state != W_NUM_EXP) {
+                            p++, state = W_NUM_EXP0;
+                        } else {
+                            VALUE_DONE(p);
+                        }
+                        break;
+                    case W_NUM_FRAC0:
+                        if (ch - '0' <= 9u) p++, state = W_NUM_FRAC;
+                        else state = W_FAIL;
+                        break;
+                    case W_NUM_EXP0:
+                        if (ch == '+' || ch == '-') p++;
+                        state = W_NUM_EXP1;
+                        break;
+                    case W_NUM_EXP1:
+                        if (ch - '0' <= 9u) p++, state = W_NUM_EXP;
+                        else state = W_FAIL;
+                        break;
+                    case W_LITERAL:
+                        if (ch == (uint32_t)(lit & 0xFFu)) {
+                            p++, lit >>= 8;
+                            if (--lit_left == 0u) VALUE_DONE(p);
+                        } else {
+                            state = W_FAIL;
+                        }
+                        break;
+                    default:
+                        state = W_FAIL;
+                        break;
+                }
+            }
+#undef VALUE_DONE
+            // the loop ends at the end of the line (every chunk has been in the lanes by then) or on a failure
+            const bool ok = state == W_END && !bad && need == conts;
+            status = !ok ? ST_FALLBACK : (have_content && content_ok) ? ST_OK : ST_NOCONTENT;
+            if (status == ST_FALLBACK) idk = ID_ABSENT, idb = ide = 0;
+            if (status != ST_OK) cpos = cdec = 0;
+        }
+        if (lane == 0) {
+            A.status[i] = status;
+            A.content_pos[i] = cpos;
+            A.content_len[i] = cdec;
+            if (A.id_kind) {
+                A.id_kind[i] = idk;
+                A.id_beg[i] = idb;
+                A.id_end[i] = ide;
+            }
+        }
+    }
+}
+
 // ---- decode: one wave per line ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t enc_utf8(uint32_t cp, uint32_t& len) {
     if (cp < 0x80u) {
@@ -639,7 +1033,15 @@ int mdd_jsonl_scan(mdd_ctx* ctx, const uint8_t* raw, uint64_t raw_bytes, const u
     A.id_kind = il ? id_kind : nullptr;
     A.id_beg = id_beg;
     A.id_end = id_end;
-    hipLaunchKernelGGL(jsonl_scan_kernel, dim3(grid_for(n_lines, 256)), dim3(256), 0, ctx->stream, A);
+    // TEST HOOK: MDD_JSONL_SCAN=thread runs the thread-per-line scanner (the first implementation, kept as the independent
+    // one the tests hold the wave scanner against)
+    const char* how = getenv("MDD_JSONL_SCAN");
+    if (how && strcmp(how, "thread") == 0) {
+        hipLaunchKernelGGL(jsonl_scan_kernel, dim3(grid_for(n_lines, 256)), dim3(256), 0, ctx->stream, A);
+    } else {
+        const uint64_t blocks = (n_lines + 3) / 4, cap = (uint64_t)ctx->cus * 6;  // 24 waves per CU: all resident (106 SGPRs)
+        hipLaunchKernelGGL(jsonl_scan_wave_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, ctx->stream, A);
+    }
     HIP_TRY(hipGetLastError());
     return MDD_OK;
 }

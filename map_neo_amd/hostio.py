@@ -420,10 +420,13 @@ def read_jsonl_batch_device(eng, paths, content_field: str, id_field=None, on_er
             ids_of[i] = hb[int(idb[i]):int(ide[i])].tobytes().decode("utf8")
         for i in np.flatnonzero(idk == 2).tolist():
             ids_of[i] = json.loads(hb[int(idb[i]):int(ide[i])].tobytes())
-    fb_docs, bad = {}, []
+    fb_docs, bad, blank = {}, [], []
     for i in fb.tolist():                                                 # lines handed back: the reference's own steps
         try:
             line = hb[int(lb[i]):int(lb[i + 1])].tobytes().decode("utf8")
+            if not line.strip():                                          # blank to Python (U+0085, U+00A0 ...: str.strip knows more
+                blank.append(i)                                           # whitespace than the device): no row, and no bad line
+                continue
             ok, rid, data = _py_line(line, content_field, id_field, False, on_error)
         except UnicodeDecodeError:
             if on_error == "raise":
@@ -436,8 +439,8 @@ def read_jsonl_batch_device(eng, paths, content_field: str, id_field=None, on_er
         if data is not None:
             fb_docs[i] = data
     bad = np.asarray(bad, dtype=np.int64)
-    if len(bad):
-        rows = rows[~np.isin(rows, bad)]
+    if len(bad) or blank:
+        rows = rows[~np.isin(rows, np.concatenate([bad, np.asarray(blank, dtype=np.int64)]))]
     file_of_line = lambda lines: np.searchsorted(first_line, lines, side="right") - 1      # noqa: E731
     n_bad = np.bincount(file_of_line(bad), minlength=len(paths)) if len(bad) else np.zeros(len(paths), dtype=np.int64)
     ids = [ids_of.get(i) for i in rows.tolist()] if id_field else [None] * len(rows)

@@ -203,3 +203,71 @@ def test_signatures_from_device_reader_equal_host_reader(engine, tmp_path):
     exp = engine.signatures(engine.to_device(buf), engine.to_device(py["offsets"]))
     import torch
     assert torch.equal(sig, exp)
+
+
+def test_wave_scanner_equals_thread_scanner_on_mutated_lines(engine, tmp_path, monkeypatch):
+    """the scan kernel (a wave per line, an automaton over 64-byte chunks) against the first implementation (a thread per line
+    walking the bytes: MDD_JSONL_SCAN=thread) on valid rows and on the same rows with bytes flipped, dropped and inserted --
+    broken escapes, invalid utf-8, unbalanced brackets, stray quotes at every chunk offset: identical status, content range,
+    decoded length and id token for every line; and what the device vouches for equals the pure-Python reader"""
+    import torch
+    from map_neo_amd.minhash import padded_size
+    rng = np.random.Generator(np.random.PCG64(11))
+    pools = [(0x20, 0x7F), (0x80, 0x7FF), (0x800, 0xD7FF), (0xE000, 0xFFFF), (0x10000, 0x10FFFF), (0x00, 0x20)]
+    base_rows = [t for t in TRICKY if "\n" not in t and "\r" not in t]
+    for i in range(600):
+        n = int(rng.integers(0, 300))
+        t = "".join(chr(int(rng.integers(*pools[int(rng.integers(0, len(pools)))]))) for _ in range(n))
+        base_rows.append(json.dumps({"k": [i, {"text": "in"}, [[], {}], -1.5e-3, True], "doc_id": [f"d{i}", i, None, {"a": i}][i % 4], "text": t,
+                                     "z": None, "pad": "x" * int(rng.integers(0, 70))}, ensure_ascii=bool(i % 2)))
+    inserts = [b"\\", b'"', b"\\u", b"\\ud83d", b"\\ude00", b"\xc3", b"\xa9", b"\xe4\xb8", b"\xf0\x9f", b"\xff", b"{", b"}", b"[", b"]", b",", b":",
+               b"\t", b"\x01", b"\x1c", b" ", b"0", b"-", b"e", b".", b"tru", b"null", b"\\x"]
+    lines = []
+    for r in base_rows:
+        raw = r.encode("utf8")
+        lines.append(raw)
+        for _ in range(12):
+            m = bytearray(raw)
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, len(m) + 1))
+                kind = int(rng.integers(0, 3))
+                if kind == 0 and pos < len(m):
+                    del m[pos]
+                elif kind == 1 and pos < len(m):
+                    m[pos] = int(rng.integers(0, 256))
+                else:
+                    m[pos:pos] = inserts[int(rng.integers(0, len(inserts)))]
+            lines.append(bytes(m).replace(b"\n", b" ").replace(b"\r", b" "))
+    data = b"\n".join(lines) + b"\n"
+    buf = np.zeros(padded_size(len(data)), np.uint8)
+    buf[: len(data)] = np.frombuffer(data, np.uint8)
+    raw = engine.to_device(buf)
+    got = {}
+    for how in ("thread", "wave"):
+        monkeypatch.setenv("MDD_JSONL_SCAN", how)
+        x = engine.jsonl_extract(raw, len(data), "text", "doc_id")
+        torch.cuda.synchronize()
+        got[how] = x
+    a, b = got["thread"], got["wave"]
+    assert a["n_lines"] == b["n_lines"] == len(lines)
+    diff = np.flatnonzero(a["status"] != b["status"])
+    assert diff.size == 0, [(int(i), int(a["status"][i]), int(b["status"][i]), lines[int(i)][:200]) for i in diff[:5]]
+    assert (a["status"] == 0).sum() > 800 and (a["status"] == 2).sum() > 800 and (a["status"] == 1).sum() > 20, np.bincount(a["status"])
+    for key in ("ok_lines", "id_kind", "id_beg", "id_end"):
+        assert (a[key] == b[key]).all(), key
+    assert a["text_bytes"] == b["text_bytes"] and torch.equal(a["offsets"], b["offsets"]) and torch.equal(a["text"], b["text"])
+    monkeypatch.delenv("MDD_JSONL_SCAN")
+    # (the pure-Python reader opens the shard as utf-8 text: it gets the lines that decode, plus two that are blank to
+    # str.strip but not to the device)
+    valid = []
+    for ln in lines:
+        try:
+            ln.decode("utf8")
+            valid.append(ln)
+        except UnicodeDecodeError:
+            pass
+    assert len(valid) > len(lines) // 2
+    valid[5:5] = ["\u0085\u00a0".encode("utf8"), b"\x1c \x0b"]
+    p = str(tmp_path / "m.jsonl")
+    open(p, "wb").write(b"\n".join(valid) + b"\n")
+    _both(engine, p)
