@@ -355,7 +355,7 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          it can only take part in a group when the k-gram its bytes select -- the one with the smallest hash among
  *          those starting in its first 19 bytes, leftmost on ties -- occurs twice in the corpus.  The selected k-grams
  *          ("anchors", one per ~10 windows) are sorted and grouped like windows (same workspaces; ent_cap >=
- *          max(windows / 4, (text_bytes + 71) / 8) + the slack above is ample: anchors beyond it switch the filter
+ *          max(windows / 6, (text_bytes + 71) / 8) + the slack above is ample: anchors beyond it switch the filter
  *          off, they do not fail the call), and cand[p] = 1 for every byte position p with a repeated anchor in
  *          [p, p + 18].  *n_cand (DEVICE) = number of flagged positions, an upper bound of the windows mark_sorted
  *          will sort.  Asynchronous.  50 <= window <= 128 (a window of w code points has >= w bytes; below 50 bytes
@@ -364,7 +364,10 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          around an anchor are compared with those around the earlier anchors of its key, which decides all 19 windows
  *          that can select it; their marks go straight into dup and only what that comparison cannot vouch for (bytes
  *          >= 0x80 in the region, keys with more than 32 anchors, leaves of more than 768 anchors) is flagged in cand for
- *          mark_sorted.  *n_cand == 0 then means dup is final.  On C2 (1 M documents, 15 % near-copies) 2 % of the
+ *          mark_sorted.  *n_cand == 0 then means dup is final.  The anchors' leaves follow the size of the text (2^20
+ *          leaves up to ~2.2 GB, 2^21 / 2^22 beyond) and a leaf above 384 anchors -- every leaf once a call holds more
+ *          than ~9 GB -- is settled in rounds over shares of the tag space, so one call takes any text below 2^36 bytes
+ *          (27 GB / 12.5 M documents: 0.50 s for the stage, one pass).  On C2 (1 M documents, 15 % near-copies) 2 % of the
  *          windows remain for mark_sorted and the stage takes 29.5 instead of 79 ms (filter alone, window != 50: 28 %
  *          remain, 61 ms). */
 #define MDD_SUBSTR_SORTED_WS_WORDS 11672587ull
@@ -425,7 +428,10 @@ int mdd_gather_docs(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *                content_len = its decoded utf-8 length (both 0 unless status is OK), and -- when id_key is not NULL --
  *                id_kind (MDD_IO_ID_* of include/mdd_io.h: 0 absent / null, 1 plain string, 2 JSON token) with the byte
  *                range [id_beg, id_end) of the id inside raw.  Keys: HOST strings of 1..64 bytes that need no JSON
- *                escaping (otherwise MDD_ERR_UNSUPPORTED: use the host reader).  The last duplicate key wins.
+ *                escaping (otherwise MDD_ERR_UNSUPPORTED: use the host reader).  The last duplicate key wins.  One wave
+ *                per line, 64 bytes per step (string bodies, digit runs and whitespace are crossed with ballots).  TEST
+ *                HOOK: the environment variable MDD_JSONL_SCAN=thread selects the first implementation (one thread
+ *                per line), which the tests hold the wave scanner against.
  *   decode       the decoded content of every OK line at out_text[out_offsets[i] ..) (out_offsets = the caller's
  *                exclusive prefix sum of content_len; nothing is written at or beyond out_capacity): escapes,
  *                \uXXXX and surrogate pairs resolved -- the packed utf-8 mdd_signatures consumes. */

@@ -966,7 +966,7 @@ constexpr uint32_t AN_MINWIN = AN_KG + AN_SPAN - 1;   // = 50: the smallest wind
 constexpr uint32_t AN_LANES = 50;                     // lanes of a step whose 4 positions get a window minimum: their windows reach
                                                       // position 4 * 49 + 3 + 18 = 217 (lane 54), whose k-gram ends in lane 62's dword
 static_assert(AN_MINWIN == 50, "mdd_substr_candidates: the filter is defined for windows of at least 50 code points");
-constexpr int AN_D1_BITS = 9;                         // level-1 digit of an anchor (a window entry has 11)
+constexpr int AN_D1_BITS = 9;                         // level-1 digit of an anchor: 9 bits up to ~2.2 GB of text, 10 / 11 beyond (a window entry has 11)
 constexpr uint32_t AN_C0 = 0x9E3779B1u, AN_C1 = 0x85EBCA77u, AN_C2 = 0xC2B2AE3Du, AN_C3 = 0x27D4EB2Fu;
 
 // lane l reads x of lane l + n (the top n lanes read the bottom ones: their positions are never used)
@@ -985,14 +985,27 @@ __device__ __forceinline__ uint64_t anchor_key(const uint32_t (&w)[8]) {
     const uint64_t u = a ^ ((b << 32) | (b >> 32));
     return (uint64_t)(uint32_t)u * AN_C0 + (uint64_t)(uint32_t)(u >> 32) * 0x9FB21C651E98DF25ull;
 }
-// what is sorted: [d2:11 | tag:17 | pos:36] like a window entry; d1 has 9 bits here (512 partitions x 2048 = 2^20 leaves of
-// ~200 anchors: small leaves mean small LDS tables and many resident waves for anchor_resolve_kernel, which waits on memory).  The ORDER among a window's k-grams uses bits 31..8 of the key, so d1 / d2 / tag avoid the top of the low
-// half (anchors are minima: those bits are mostly zero).
-__device__ __forceinline__ uint32_t anchor_d1(uint64_t key) { return (uint32_t)(key >> (64 - AN_D1_BITS)); }
-__device__ __forceinline__ uint64_t anchor_entry(uint64_t key, uint64_t pos) {
+// what is sorted: [d2:11 | tag:17 | pos:36] like a window entry; d1 has 9 bits up to ~2.2 GB of text (512 partitions x 2048 = 2^20
+// leaves of ~200 anchors: small leaves mean small LDS tables and many resident waves for anchor_resolve_kernel, which waits
+// on memory) and 10 or 11 bits beyond (2^21 / 2^22 leaves: the leaves stay small; an_d1_bits).  The ORDER among a window's
+// k-grams uses bits 31..8 of the key, so d1 / d2 / tag avoid the top of the low half (anchors are minima: those bits are
+// mostly zero).
+__device__ __forceinline__ uint32_t anchor_d1(uint64_t key, uint32_t bits) { return (uint32_t)(key >> (64 - bits)); }
+__device__ __forceinline__ uint64_t anchor_entry(uint64_t key, uint64_t pos, uint32_t bits) {
     const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-    const uint64_t d2tag = ((uint64_t)(hi & 0x007FFFFFu) << 5) | ((lo >> 8) & 0x1Fu);  // 23 + 5 = 11 + 17 bits below the 9 of d1
+    // 11 + 17 bits below the `bits` of d1: the rest of the high half, then bits 8.. of the low half (bits = 9: 23 + 5)
+    const uint64_t d2tag = ((uint64_t)(hi & (0xFFFFFFFFu >> bits)) << (bits - 4u)) | ((lo >> 8) & ((1u << (bits - 4u)) - 1u));
     return (d2tag << POS_BITS) | pos;
+}
+// level-1 digit width for a text of this size: ~one anchor per 10 bytes, ~200 per leaf
+inline uint32_t an_d1_bits(uint64_t text_bytes) {
+    uint32_t bits = AN_D1_BITS;
+    while (bits < (uint32_t)D1_BITS && text_bytes / 10 > (220ull << (bits + D2_BITS))) bits++;
+    if (const char* knob = getenv("MDD_SUBSTR_D1_BITS")) {  // testing: more leaves than the size asks for, or so few (4 bits: 2^15)
+        const int b = atoi(knob);                           // that a moderate text fills them beyond RS_MAX
+        if (b >= 4 && b <= D1_BITS) bits = (uint32_t)b;
+    }
+    return bits;
 }
 
 struct AnchorArgs {
@@ -1012,6 +1025,7 @@ struct AnchorArgs {
     unsigned int* hist1;
     unsigned long long* overflow;  // anchors that found no room: the filter then lets every window through (smear_kernel)
     uint32_t batch_shift;
+    uint32_t d1_bits;              // an_d1_bits(text_bytes)
 };
 
 // One wave per document (or segment of a long one), persistent, batched claims -- the skeleton of emit_kernel.  A step
@@ -1155,9 +1169,9 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) anchor_kernel(AnchorArgs A) {
                 if (F & (0xFFu << (8 * j))) {
                     const uint64_t key = ((uint64_t)keyhi[j] << 32) | keylo[j];
                     if (o < A.ent_cap) {
-                        A.ent[o] = anchor_entry(key, 4 * my_dw + j);
-                        A.d1[o] = (uint16_t)anchor_d1(key);
-                        atomicAdd(&h1[anchor_d1(key)], 1u);
+                        A.ent[o] = anchor_entry(key, 4 * my_dw + j, A.d1_bits);
+                        A.d1[o] = (uint16_t)anchor_d1(key, A.d1_bits);
+                        atomicAdd(&h1[anchor_d1(key, A.d1_bits)], 1u);
                     } else {
                         atomicAdd(A.overflow, 1ull);
                     }
@@ -1337,18 +1351,27 @@ constexpr uint32_t RS_NIL = 511u;    // end of a chain (member indices stay belo
 static_assert(RS_MAX <= RS_NIL, "member index and NIL share 9 bits");
 __device__ __forceinline__ uint32_t rs_home(unsigned long long val) { return ((uint32_t)(val >> POS_BITS) * 0x9E3779B1u) >> (32 - 9); }
 static_assert(RS_SLOTS == 512, "rs_home yields 9 bits");
+// BIG = the variant for leaves above RS_MAX anchors (a text beyond ~9 GB per call: even 2^22 leaves then hold more than the
+// table takes; or heavy repetition): such a leaf is grouped in rounds over shares of the tag space -- equal keys have equal
+// tags and meet in one round -- and a member is numbered inside its round, midx[] mapping the number back to the leaf.
+template <bool BIG>
 struct ResolveLds {
     unsigned long long tab[RS_SLOTS];  // [d2 | tag | position] of the group's lowest anchor; all-ones = empty
-    uint32_t head[RS_SLOTS];           // [members : 23 | index (inside the leaf) of the most recently chained member : 9]
+    uint32_t head[RS_SLOTS];           // [members : 23 | index (inside the leaf / round) of the most recently chained member : 9]
     uint16_t next[RS_MAX];
     uint32_t fb[RS_SLOTS / 32];        // groups handed to the window sort
     unsigned long long lval[RS_LIST];
     uint16_t lslot[RS_LIST];
-    uint16_t lidx[RS_LIST];              // index of the member inside the leaf
+    uint16_t lidx[RS_LIST];              // index of the member inside the leaf / round
     uint32_t clone[RS_MAX / 32];         // members that add nothing to their group's lowest anchor (see drain)
+    uint16_t midx[BIG ? RS_MAX : 1];     // BIG: offset inside the leaf of the round's member
 };
-constexpr unsigned RS_WAVES_PER_CU = 18;
-static_assert(RS_WAVES_PER_CU * sizeof(ResolveLds) <= 160 * 1024, "the resolve kernel's workgroups must all be resident");
+constexpr unsigned RS_WAVES_PER_CU = 18, RS_WAVES_PER_CU_BIG = 16;
+constexpr uint32_t RS_ROUND = 320;       // BIG: anchors per round, on average (their number is Poisson: 384 is 3.6 sigma away; a
+                                         // share that overflows goes to the window sort -- rare, and fewer rounds are worth more)
+constexpr uint32_t RS_BIG_MAX = 0xFFFFu; // BIG: a leaf above this many anchors is flagged whole (midx is 16 bits wide)
+static_assert(RS_WAVES_PER_CU * sizeof(ResolveLds<false>) <= 160 * 1024 && RS_WAVES_PER_CU_BIG * sizeof(ResolveLds<true>) <= 160 * 1024,
+              "the resolve kernel's workgroups must all be resident");
 struct ResolveArgs {
     const uint64_t* ent;
     const uint64_t* off2;
@@ -1421,8 +1444,9 @@ __device__ __forceinline__ uint32_t region_match(const uint32_t (&Ra)[18], const
     return (0x7FFFFu >> (18u - r)) & (0x7FFFFu << (18u - l)) & 0x7FFFFu;  // bits 18 - l .. r
 }
 
+template <bool BIG>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) anchor_resolve_kernel(ResolveArgs A) {
-    __shared__ ResolveLds L;
+    __shared__ ResolveLds<BIG> L;
     const uint32_t lane = lane_id();
     auto find_slot = [&](unsigned long long val) -> uint32_t {  // the slot of val's group (val has been inserted)
         uint32_t slot = rs_home(val);
@@ -1432,19 +1456,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
     for (uint32_t leaf = blockIdx.x; leaf < A.n_leaves; leaf += gridDim.x) {
         const uint64_t lo = A.off2[leaf], hi = A.off2[leaf + 1];
         if (hi - lo < 2) continue;
-        if (hi - lo > RS_MAX) {  // cannot happen to unrelated keys (a leaf holds ~400): heavy repetition, the window sort's business
+        if ((hi - lo > RS_MAX) != BIG) continue;  // (the other instance of this kernel takes the leaf)
+        if (BIG && hi - lo > RS_BIG_MAX) {         // heavy repetition: the window sort's business
             for (uint64_t i = lo + lane; i < hi; i += 64) {
                 const uint64_t pos = A.ent[i] & POS_M;
                 if (pos < A.text_bytes) A.flag[pos] = 1;
             }
             continue;
         }
-        unsigned long long e[RS_CH];
-#pragma unroll
-        for (uint32_t k = 0; k < RS_CH; k++) {
-            const uint64_t i = lo + (uint64_t)k * 64 + lane;
-            e[k] = i < hi ? A.ent[i] : ENT_INVALID;
-        }
+        // BIG: round r takes the anchors whose tag lies in share r of the tag space
+        const uint32_t rounds = BIG ? ((uint32_t)(hi - lo) + RS_ROUND - 1) / RS_ROUND : 1u;
+        auto mine = [&](unsigned long long val, uint32_t r) -> bool {
+            return !BIG || ((((uint32_t)(val >> POS_BITS) & 0xFFFFu) * rounds) >> 16) == r;
+        };
+      for (uint32_t round = 0; round < rounds; round++) {
 #pragma unroll
         for (int i = 0; i < RS_SLOTS / 64; i++) {
             L.tab[i * 64 + lane] = ENT_INVALID;
@@ -1454,13 +1479,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
         if (lane < RS_MAX / 32) L.clone[lane] = 0;
         lds_sync();
         // ---- 1. groups: the slot keeps the lowest anchor of its key, the chain every member
-#pragma unroll 1
-        for (uint32_t k = 0; k < RS_CH; k++) {
-            const unsigned long long val = e[0];
-#pragma unroll
-            for (uint32_t j = 0; j + 1 < RS_CH; j++) e[j] = e[j + 1];
-            e[RS_CH - 1] = ENT_INVALID;
-            if (val == ENT_INVALID) continue;
+        auto insert = [&](unsigned long long val, uint32_t idx) {
             uint32_t slot = rs_home(val);
             for (uint32_t probe = 0; probe < RS_SLOTS; probe++) {
                 const unsigned long long cur = atomicCAS(&L.tab[slot], ENT_INVALID, val);
@@ -1472,7 +1491,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
                 slot = (slot + 1) & (RS_SLOTS - 1);
             }
             // chain this member in: head = [members so far : 23 | most recent member : 9], updated as one word
-            const uint32_t idx = k * 64 + lane;
             uint32_t old = L.head[slot];
             for (;;) {
                 const uint32_t seen = atomicCAS(&L.head[slot], old, (((old >> 9) + 1u) << 9) | idx);
@@ -1480,6 +1498,46 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
                 old = seen;
             }
             L.next[idx] = (uint16_t)(old & RS_NIL);
+        };
+        if constexpr (!BIG) {
+            unsigned long long e[RS_CH];
+#pragma unroll
+            for (uint32_t k = 0; k < RS_CH; k++) {
+                const uint64_t i = lo + (uint64_t)k * 64 + lane;
+                e[k] = i < hi ? A.ent[i] : ENT_INVALID;
+            }
+#pragma unroll 1
+            for (uint32_t k = 0; k < RS_CH; k++) {
+                const unsigned long long val = e[0];
+#pragma unroll
+                for (uint32_t j = 0; j + 1 < RS_CH; j++) e[j] = e[j + 1];
+                e[RS_CH - 1] = ENT_INVALID;
+                if (val == ENT_INVALID) continue;
+                insert(val, k * 64 + lane);
+            }
+        } else {
+            uint32_t n_mem = 0;
+            for (uint64_t c0 = lo; c0 < hi; c0 += 64) {
+                const uint64_t i = c0 + lane;
+                const unsigned long long val = i < hi ? A.ent[i] : ENT_INVALID;
+                const bool take = val != ENT_INVALID && mine(val, round);
+                const uint64_t tb = __ballot(take);
+                const uint32_t idx = n_mem + below(tb);
+                if (take && idx < RS_MAX) {
+                    L.midx[idx] = (uint16_t)(i - lo);
+                    insert(val, idx);
+                }
+                n_mem += (uint32_t)__popcll(tb);
+            }
+            if (n_mem > RS_MAX) {  // more than the table takes in one share (it holds 320 on average): the window sort's business
+                for (uint64_t i = lo + lane; i < hi; i += 64) {
+                    const unsigned long long val = A.ent[i];
+                    const uint64_t pos = val & POS_M;
+                    if (val != ENT_INVALID && mine(val, round) && pos < A.text_bytes) A.flag[pos] = 1;
+                }
+                lds_sync();
+                continue;
+            }
         }
         lds_sync();
         // ---- 2. members with an earlier anchor in their group, 64 at a time with every lane busy
@@ -1526,7 +1584,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
                     const uint32_t va = left | marks;
                     for (uint32_t i = L.head[slot] & RS_NIL; left && i != RS_NIL; i = L.next[i]) {
                         if ((L.clone[i >> 5] >> (i & 31u)) & 1u) continue;
-                        const uint64_t b2 = A.ent[lo + i] & POS_M;
+                        const uint64_t b2 = A.ent[lo + (BIG ? (uint32_t)L.midx[i] : i)] & POS_M;
                         if (b2 >= a || b2 == b) continue;
                         if (b2 < 20) {
                             vouch = false;
@@ -1571,22 +1629,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
             lds_sync();
             n_list = rest;
         };
+        uint32_t n_seen = 0;  // BIG: members of the round met so far (the numbering of step 1)
         for (uint64_t c0 = lo; c0 < hi; c0 += 64) {
             const uint64_t i = c0 + lane;
-            bool work = false;
+            bool work = false, take = false;
             unsigned long long val = ENT_INVALID;
             uint32_t slot = 0;
             if (i < hi) {
                 val = A.ent[i];  // (second read: from the L2)
-                slot = find_slot(val);
-                work = L.tab[slot] != val;  // not the group's lowest anchor (a lone anchor is its group's lowest)
+                take = val != ENT_INVALID && mine(val, round);
+                if (take) {
+                    slot = find_slot(val);
+                    work = L.tab[slot] != val;  // not the group's lowest anchor (a lone anchor is its group's lowest)
+                }
             }
             const uint64_t wb = __ballot(work);
+            uint32_t member = (uint32_t)(i - lo);
+            if constexpr (BIG) {
+                const uint64_t tb = __ballot(take);
+                member = n_seen + below(tb);
+                n_seen += (uint32_t)__popcll(tb);
+            }
             if (work) {
                 const uint32_t at = n_list + below(wb);
                 L.lval[at] = val;
                 L.lslot[at] = (uint16_t)slot;
-                L.lidx[at] = (uint16_t)(i - lo);
+                L.lidx[at] = (uint16_t)member;
             }
             n_list += (uint32_t)__popcll(wb);
             if (n_list > RS_LIST - 64) drain(false);
@@ -1598,12 +1666,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
         if (__ballot(any_fb)) {
             for (uint64_t i = lo + lane; i < hi; i += 64) {
                 const unsigned long long val = A.ent[i];
+                if (val == ENT_INVALID || !mine(val, round)) continue;
                 const uint32_t slot = find_slot(val);
                 const uint64_t pos = val & POS_M;
                 if (((L.fb[slot >> 5] >> (slot & 31u)) & 1u) && pos < A.text_bytes) A.flag[pos] = 1;
             }
         }
         lds_sync();
+      }  // rounds
     }
 }
 
@@ -1793,6 +1863,7 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     E.n_ent = W.counters;
     E.hist1 = W.hist1;
     E.overflow = W.counters + 7;
+    E.d1_bits = an_d1_bits(text_bytes);
     uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
     while ((1ull << E.batch_shift) < w / 4) E.batch_shift++;  // (batches of 32 until ~8 items per wave are left: see emit_kernel)
     hipLaunchKernelGGL(anchor_kernel, dim3((unsigned)((w + EMIT_WAVES - 1) / EMIT_WAVES)), dim3(64 * EMIT_WAVES), 0, st, E);
@@ -1803,7 +1874,7 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     }
     uint8_t* flag = reinterpret_cast<uint8_t*>(ent_b);
     HIP_TRY(hipMemsetAsync(flag, 0, text_bytes + 64, st));
-    const uint32_t n_leaves_a = (1u << AN_D1_BITS) * (uint32_t)BINS2;  // anchors carry a 9-bit level-1 digit
+    const uint32_t n_leaves_a = (1u << E.d1_bits) * (uint32_t)BINS2;  // anchors carry a 9- to 11-bit level-1 digit
     if (resolve && !getenv("MDD_SUBSTR_NO_RESOLVE")) {     // (the knob: A/B runs and tests of the filter-only path)
         ResolveArgs R{};
         R.ent = ent_a;
@@ -1819,7 +1890,9 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
             const int g = atoi(knob);
             if (g >= 1 && g <= (int)RS_MAX) R.max_group = (uint32_t)g;
         }
-        hipLaunchKernelGGL(anchor_resolve_kernel, dim3((unsigned)ctx->cus * RS_WAVES_PER_CU), dim3(64), 0, st, R);
+        hipLaunchKernelGGL(anchor_resolve_kernel<false>, dim3((unsigned)ctx->cus * RS_WAVES_PER_CU), dim3(64), 0, st, R);
+        // leaves above RS_MAX anchors (none at ~200 per leaf; all of them when a call holds more than ~9 GB of text)
+        hipLaunchKernelGGL(anchor_resolve_kernel<true>, dim3((unsigned)ctx->cus * RS_WAVES_PER_CU_BIG), dim3(64), 0, st, R);
     } else {
         hipLaunchKernelGGL(anchor_leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, ent_a, W.off2, n_leaves_a, flag,
                            text_bytes);

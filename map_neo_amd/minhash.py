@@ -461,9 +461,9 @@ class Engine:
             n_sort = n_win                              # windows the passes have to sort
             if window >= 50 and self.substr_filter:
                 # candidate filter (mdd_substr_candidates): only windows whose selected 32-byte k-gram occurs twice in the
-                # corpus can repeat; one anchor per ~10 windows goes through the same sort first.  A quarter of the windows
+                # corpus can repeat; one anchor per ~10 windows goes through the same sort first.  A sixth of the windows
                 # is ample room for them (beyond it the filter switches itself off: every position comes back flagged).
-                cap_a = max(n_win // 4, (text_bytes + 71) // 8) + slack
+                cap_a = max(n_win // 6, (text_bytes + 71) // 8) + slack      # (a sixth: at C4's 27 GB per GPU a quarter was 40 GB more to map)
                 cap_a = min(cap_a, max(slack + (text_bytes + 71) // 8, table_bytes // per_win))
                 ent_a, ent_b = self.empty(cap_a, torch.int64), self.empty(cap_a, torch.int64)
                 d1 = self.empty(cap_a, torch.int16)

@@ -475,6 +475,47 @@ def test_substr_resolved_anchors_clusters_with_edits_vs_oracle(sorted_method):
             engine.set_segment_bytes(0)
 
 
+def test_substr_anchor_leaves_of_every_size(sorted_method, monkeypatch):
+    """the anchors' level-1 digit grows with the text (9 .. 11 bits: 2^20 .. 2^22 leaves) and leaves above 384 anchors are
+    resolved in rounds over shares of the tag space (anchor_resolve_kernel<true>: a call with more than ~9 GB of text).
+    MDD_SUBSTR_D1_BITS forces both on small inputs: 11 bits, and 4 bits (2^15 leaves: ~500 anchors per leaf for 160 MB of
+    text, three rounds each).  Against the oracle on clusters of edited copies, against the table method at scale; and the
+    rounds must RESOLVE, not hand everything to the window sort"""
+    import torch
+    from map_neo_amd import corpus
+    engine = sorted_method
+    rng = np.random.Generator(np.random.PCG64(77))
+    alpha = [chr(c) for c in range(0x61, 0x7B)] + [" "] * 5
+    docs = []
+    for cl in range(40):
+        base = "".join(rng.choice(alpha, int(rng.integers(60, 700))))
+        for c in range(int(rng.integers(1, 12))):
+            t = list(base)
+            for _ in range(int(rng.integers(0, 4))):
+                t[int(rng.integers(0, len(t)))] = "#"
+            docs.append("".join(t))
+    rows = [(docs[int(i)], k) for k, i in enumerate(rng.permutation(len(docs)))]
+    exp = RX.exact_substr_dedup(rows, 50, 20)
+    for bits in ("4", "10", "11"):
+        monkeypatch.setenv("MDD_SUBSTR_D1_BITS", bits)
+        assert exact.exact_substr_dedup(engine, rows, 50, 20) == exp, bits
+    monkeypatch.delenv("MDD_SUBSTR_D1_BITS")
+    spec = corpus.CorpusSpec(80_000, 2048, lang="en", seed=12)
+    text, offs = corpus.generate_chunked(spec, engine.device)
+    ref = engine.substr_dedup(text, offs, 50, 20, method="table")
+    n = int(ref[1][-1].item())
+    assert 0 < n < int(offs[-1].item())
+    a = engine.substr_dedup(text, offs, 50, 20, method="sorted")
+    n_sort_default, n_win = engine.last_substr_candidates
+    assert torch.equal(a[1], ref[1]) and torch.equal(a[2], ref[2]) and torch.equal(a[0][:n], ref[0][:n])
+    for bits in ("4", "11"):
+        monkeypatch.setenv("MDD_SUBSTR_D1_BITS", bits)
+        b = engine.substr_dedup(text, offs, 50, 20, method="sorted")
+        n_sort, _ = engine.last_substr_candidates
+        assert torch.equal(b[1], ref[1]) and torch.equal(b[2], ref[2]) and torch.equal(b[0][:n], ref[0][:n]), bits
+        assert n_sort <= 1.5 * n_sort_default + 1000 and n_sort < 0.1 * n_win, (bits, n_sort, n_sort_default, n_win)
+
+
 def test_para_doc_sums_equal_the_text_pass(engine):
     """mdd_para_doc_sums (per-document sums from the units + the code points mdd_exact_group_cps counts) ==
     mdd_para_compact_count (the same sums from a pass over the text), on multi-byte text with empty paragraphs, empty

@@ -33,14 +33,16 @@ for seed in range(n_seeds):
     exp = RX.exact_substr_dedup(rows, window, min_length)
     eng.set_segment_bytes(seg)
     try:
-        for method in ("table", "sorted"):
-            eng.substr_method = method
+        for method in ("table", "sorted", "sorted-nofilter"):      # sorted: anchors + in-leaf resolution from 50 code points on (round 3)
+            eng.substr_method = method.split("-")[0]
+            eng.substr_filter = method != "sorted-nofilter"
             got = exact.exact_substr_dedup(eng, rows, window, min_length)
             if got != exp:
                 bad += 1
                 print(f"seed {seed}: MISMATCH method={method} window={window} min_length={min_length} seg={seg}", flush=True)
     finally:
         eng.substr_method = "auto"
+        eng.substr_filter = True
         eng.set_segment_bytes(0)
     ids = [int(i) for i in rng.permutation(len(docs))]
     prow = list(zip(ids, docs))
