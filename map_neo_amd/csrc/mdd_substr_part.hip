@@ -1382,6 +1382,10 @@ struct ResolveArgs {
     uint8_t* dup;
     uint8_t* flag;
     uint32_t max_group;  // RS_GROUP (a tuning knob lowers / raises it: MDD_SUBSTR_GROUP)
+    uint32_t big_hi;     // a leaf of RS_MAX + 1 .. big_hi anchors is settled in rounds (anchor_resolve_kernel<true>), a larger one
+                         // is flagged whole.  RS_MAX when the leaves are expected to hold ~200 (a leaf above that is heavy repetition,
+                         // whose groups exceed max_group anyway: rounds over it were 3.5 ms of nothing on C2); a few times the
+                         // expected size when the text outgrows 2^22 leaves
 };
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -1456,12 +1460,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
     for (uint32_t leaf = blockIdx.x; leaf < A.n_leaves; leaf += gridDim.x) {
         const uint64_t lo = A.off2[leaf], hi = A.off2[leaf + 1];
         if (hi - lo < 2) continue;
-        if ((hi - lo > RS_MAX) != BIG) continue;  // (the other instance of this kernel takes the leaf)
-        if (BIG && hi - lo > RS_BIG_MAX) {         // heavy repetition: the window sort's business
-            for (uint64_t i = lo + lane; i < hi; i += 64) {
-                const uint64_t pos = A.ent[i] & POS_M;
-                if (pos < A.text_bytes) A.flag[pos] = 1;
-            }
+        if (BIG && (hi - lo <= RS_MAX || hi - lo > A.big_hi)) continue;  // (the other instance of this kernel takes the leaf)
+        if (!BIG && hi - lo > RS_MAX) {
+            if (hi - lo > A.big_hi)                // heavy repetition: the window sort's business
+                for (uint64_t i = lo + lane; i < hi; i += 64) {
+                    const uint64_t pos = A.ent[i] & POS_M;
+                    if (pos < A.text_bytes) A.flag[pos] = 1;
+                }
             continue;
         }
         // BIG: round r takes the anchors whose tag lies in share r of the tag space
@@ -1890,9 +1895,18 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
             const int g = atoi(knob);
             if (g >= 1 && g <= (int)RS_MAX) R.max_group = (uint32_t)g;
         }
+        // expected anchors per leaf (~one per 10 bytes): up to ~250 every leaf fits the table and one above RS_MAX is heavy
+        // repetition; beyond (more than ~9 GB of text: 2^22 leaves is all there is) leaves up to 4 x the expected size are
+        // settled in rounds by the second instance
+        const uint64_t per_leaf = text_bytes / 10 / n_leaves_a;
+        R.big_hi = RS_MAX;
+        if (per_leaf > 250 || getenv("MDD_SUBSTR_D1_BITS")) {      // (the test hook forces few leaves on small inputs)
+            const uint64_t hi4 = 4 * per_leaf > 1024 ? 4 * per_leaf : 1024;
+            R.big_hi = (uint32_t)(hi4 < RS_BIG_MAX ? hi4 : RS_BIG_MAX);
+        }
         hipLaunchKernelGGL(anchor_resolve_kernel<false>, dim3((unsigned)ctx->cus * RS_WAVES_PER_CU), dim3(64), 0, st, R);
-        // leaves above RS_MAX anchors (none at ~200 per leaf; all of them when a call holds more than ~9 GB of text)
-        hipLaunchKernelGGL(anchor_resolve_kernel<true>, dim3((unsigned)ctx->cus * RS_WAVES_PER_CU_BIG), dim3(64), 0, st, R);
+        if (R.big_hi > RS_MAX)
+            hipLaunchKernelGGL(anchor_resolve_kernel<true>, dim3((unsigned)ctx->cus * RS_WAVES_PER_CU_BIG), dim3(64), 0, st, R);
     } else {
         hipLaunchKernelGGL(anchor_leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, ent_a, W.off2, n_leaves_a, flag,
                            text_bytes);
