@@ -546,6 +546,12 @@ __global__ void __launch_bounds__(256) jsonl_scan_wave_kernel(ScanArgs A) {
             uint64_t p = beg, base = beg;
             bool loaded = false;
             uint32_t c = ' ';
+            // the NEXT chunk's bytes are requested while this one is worked on: a wave crosses its line chunk by chunk, and a
+            // load issued only when the chunk is needed left it waiting a memory round trip per 64 bytes (17 ms per 2.2 GB)
+            // (unconditional loads at an address clamped to the buffer's padding, masked when consumed: a load under a branch
+            // makes the compiler wait for it where the branch joins)
+            auto fetch = [&](uint64_t q) -> uint32_t { return *reinterpret_cast<const mdd_u32_a1*>(b + (q < A.raw_bytes ? q : A.raw_bytes)); };
+            uint32_t w_next = fetch(beg + lane);
             uint64_t Q = 0, S = 0, CTRL = 0, NWS = 0, LONE = 0, C0 = 0, C1 = 0, C2 = 0, DIG = 0;
             uint64_t carry_s = 0, prev_S = 0, prev_SU = 0;  // previous chunk: its last byte starts an escape; its escape starts; its \u starts
             uint64_t need = 0, conts = 0;                   // continuation bytes the line's leads ask for / continuation bytes seen
@@ -576,7 +582,8 @@ __global__ void __launch_bounds__(256) jsonl_scan_wave_kernel(ScanArgs A) {
                     const bool in = q < end;
                     // the lane's byte and the three behind it (bytes past `end` are the next line's or the buffer's padding:
                     // every use below checks positions against `end`)
-                    const uint32_t w = in ? *reinterpret_cast<const mdd_u32_a1*>(b + q) : 0x20202020u;
+                    const uint32_t w = in ? w_next : 0x20202020u;
+                    w_next = fetch(q + 64);
                     c = w & 0xFFu;
                     const uint32_t c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu, c3 = w >> 24;
                     bool badlane = false;
@@ -594,7 +601,20 @@ __global__ void __launch_bounds__(256) jsonl_scan_wave_kernel(ScanArgs A) {
                         conts += __builtin_popcountll(__ballot((c & 0xC0u) == 0x80u));
                         need += __builtin_popcountll(__ballot(k & 1u)) + 2 * __builtin_popcountll(__ballot(k & 2u));
                     }
+                    if (__ballot(badlane)) bad = true;
+                    badlane = false;
                     const uint64_t B = __ballot(c == '\\');
+                    // the common chunk: 64 bytes of a string body without a quote, a backslash or a control character, no
+                    // escape reaching in from the chunk before.  Nothing else has to be known about it (the automaton's
+                    // masks and its dispatch are ~200 scalar instructions per chunk, and the scalar unit is what this
+                    // kernel waits for): 64 more decoded bytes, on to the next chunk
+                    if (state == W_STRING && p == base && base + 64 <= end && !(B | carry_s | prev_SU) &&
+                        !__ballot(c == '"' || c < 0x20u)) {
+                        str_n += 64;
+                        p = base + 64;
+                        prev_S = 0;
+                        continue;
+                    }
                     uint64_t body = 0, SU = 0;
                     S = 0, LONE = 0;
                     if (B || carry_s || prev_SU) {
@@ -899,9 +919,12 @@ __global__ void __launch_bounds__(256) jsonl_decode_kernel(const uint8_t* __rest
         const uint64_t start = content_pos[i] + 1;  // first byte after the opening quote
         uint64_t done = out_offs[i];
         uint64_t carry_s = 0, prev_su = 0;  // previous chunk: its last byte starts an escape; its \u starters
+        // (requested a chunk ahead, as in the scan: unconditional, the address clamped to the padding, masked when consumed)
+        uint32_t c_next = raw[start + lane < raw_bytes ? start + lane : raw_bytes];
         for (uint64_t q0 = start; q0 < raw_bytes; q0 += 64) {  // (ends at the closing quote: the scan found one)
             const uint64_t q = q0 + lane;
-            const uint32_t c = q < raw_bytes ? raw[q] : (uint32_t)'"';
+            const uint32_t c = q < raw_bytes ? c_next : (uint32_t)'"';
+            c_next = raw[q + 64 < raw_bytes ? q + 64 : raw_bytes];
             const uint64_t B = __ballot(c == '\\');
             uint32_t cnt = 1, enc = c;
             uint64_t S = 0, SU = 0, body = 0;
