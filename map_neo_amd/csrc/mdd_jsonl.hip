@@ -613,6 +613,19 @@ __global__ void __launch_bounds__(256) jsonl_scan_wave_kernel(ScanArgs A) {
                         str_n += 64;
                         p = base + 64;
                         prev_S = 0;
+                        // printable ASCII goes on 256 bytes at a time, a dword per lane (any byte >= 0x80 or < 0x20, a quote or a
+                        // backslash ends this); the chunks then continue from wherever it stopped
+                        bool moved = false;
+                        while (p + 256 <= end) {
+                            const uint32_t x = *reinterpret_cast<const mdd_u32_a1*>(b + p + 4 * lane);
+                            const uint32_t special = (x | (x - 0x20202020u)) & 0x80808080u;  // high bit set, or below 0x20 (no borrow
+                            if (__ballot((special | swar_eq(x, '"') | swar_eq(x, '\\')) != 0u)) break;  // crosses a byte >= 0x20)
+                            str_n += 256, p += 256, moved = true;
+                        }
+                        if (moved) {
+                            base = p - 64;  // (the next load takes the chunk at p)
+                            w_next = fetch(p + lane);
+                        }
                         continue;
                     }
                     uint64_t body = 0, SU = 0;
@@ -922,6 +935,17 @@ __global__ void __launch_bounds__(256) jsonl_decode_kernel(const uint8_t* __rest
         // (requested a chunk ahead, as in the scan: unconditional, the address clamped to the padding, masked when consumed)
         uint32_t c_next = raw[start + lane < raw_bytes ? start + lane : raw_bytes];
         for (uint64_t q0 = start; q0 < raw_bytes; q0 += 64) {  // (ends at the closing quote: the scan found one)
+            if (!(carry_s | prev_su)) {
+                // 256 bytes at a time while there is neither a quote nor a backslash among them: a copy, a dword per lane
+                bool moved = false;
+                while (q0 + 256 <= raw_bytes && done + 256 <= out_cap) {
+                    const uint32_t w = *reinterpret_cast<const mdd_u32_a1*>(raw + q0 + 4 * lane);
+                    if (__ballot((swar_eq(w, '"') | swar_eq(w, '\\')) != 0u)) break;
+                    *reinterpret_cast<mdd_u32_a1*>(out_text + done + 4 * lane) = w;
+                    done += 256, q0 += 256, moved = true;
+                }
+                if (moved) c_next = raw[q0 + lane < raw_bytes ? q0 + lane : raw_bytes];
+            }
             const uint64_t q = q0 + lane;
             const uint32_t c = q < raw_bytes ? c_next : (uint32_t)'"';
             c_next = raw[q + 64 < raw_bytes ? q + 64 : raw_bytes];

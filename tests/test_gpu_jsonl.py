@@ -61,6 +61,11 @@ def test_escapes_at_every_chunk_position(engine, tmp_path):
     for e in esc:
         for k in range(0, 70):
             lines.append('{"doc_id": %d, "text": "%s%s|%s%s tail"}' % (len(lines), "a" * k, e, e, "é" if k % 3 == 0 else ""))
+    # the 256-byte steps of the scan and decode kernels (printable ASCII, a dword per lane): whatever ends a run, at every
+    # alignment around the first and second step
+    for e in ['\\"', "\\n", "\\u00e9", "é", "中", "\x7f", "😀"]:
+        for k in list(range(240, 340)) + list(range(560, 600, 3)):
+            lines.append('{"doc_id": %d, "text": "%s%s%s"}' % (len(lines), "a" * k, e, "b" * 300))
     lines.append('{"text": "%s"}' % ("\\\\" * 200))
     lines.append('{"text": "%s\\""}' % ("\\\\" * 131))
     lines.append('{"text": "%s"}' % ("\\ud83d\\ude00" * 50))
@@ -68,6 +73,11 @@ def test_escapes_at_every_chunk_position(engine, tmp_path):
     open(p, "w", encoding="utf8", newline="\n").write("\n".join(lines) + "\n")
     dev, py = _both(engine, p)
     assert dev["fallback_lines"] == 0 and dev["n_bad"] == 0 and len(py["cand"]) == len(lines)
+    # ... and a raw control character there (not JSON: the line is handed back and is a bad line)
+    bad = ['{"text": "%s\x01%s"}' % ("a" * k, "b" * 300) for k in range(250, 330, 5)]
+    open(p, "w", encoding="utf8", newline="\n").write("\n".join(lines[:50] + bad) + "\n")
+    dev, py = _both(engine, p)
+    assert dev["n_bad"] == len(bad) and len(py["cand"]) == 50
 
 
 def test_random_rows_and_line_endings(engine, tmp_path):
