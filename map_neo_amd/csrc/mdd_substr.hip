@@ -278,6 +278,19 @@ __global__ void __launch_bounds__(256) compact4_kernel(const uint8_t* __restrict
                 const uint32_t cb = w & ~(w << 1) & 0x80808080u;                                    // continuation bytes (10xxxxxx)
                 const uint32_t S = in & ~cb;                                                        // code-point starts
                 const uint32_t nz = (((du & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | du) & 0x80808080u;        // dup bytes != 0
+                // The common step: 256 bytes inside the document without a mark, the most recent marked start at least W starts
+                // back and no removed code point reaching in -- every byte stays.  (Most documents hold no mark at all: the six
+                // ballots and the per-byte fates below were 2.9 + 3.3 ms of the stage for nothing.)
+                if (since >= W && !carry_gone && !__ballot(nz != 0u || in != 0x80808080u)) {
+                    if (WRITE) {
+                        store_low_bytes(out_text, done + 4 * lane, out_cap, w, 4);
+                        done += 256;
+                    } else {
+                        cnt_b += 4;
+                        cnt_c += (uint32_t)__builtin_popcount(S);
+                    }
+                    continue;
+                }
                 const uint32_t M = S & nz;                                                          // marked window starts
                 const uint32_t s = (uint32_t)__builtin_popcount(S);
                 const uint64_t B0 = __ballot(s & 1u), B1 = __ballot(s & 2u), B2 = __ballot(s & 4u);
