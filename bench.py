@@ -570,7 +570,7 @@ def main():
         # profiles/<round>_pmc_bench/summary.json, FETCH_SIZE corrected x2 as calibrated); never measured inside this
         # run (counters need rocprofv3), so the line names the file it comes from, or null if the workload differs
         traffic, traffic_source = None, None
-        for cand in ("r3_pmc_bench", "r2h_pmc_bench", "history/r2_pmc_bench", "history/r1m_pmc_bench"):
+        for cand in ("r3g_pmc_bench", "history/r3_pmc_bench", "r2h_pmc_bench", "history/r2_pmc_bench", "history/r1m_pmc_bench"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", cand, "summary.json")))
                 if pm["workload"]["text_bytes_per_gpu"] == text_bytes and pm["workload"]["docs_per_gpu"] == n_local:
