@@ -147,7 +147,7 @@ def run(args, engine_factory=None) -> dict:
         from .. import checkpoint as ckpt
 
         from ..dedup import cluster_distributed, cluster_local
-        from ..minhash import as_u32, padded_size
+        from ..minhash import as_u32, to_padded_device
         backend = os.environ.get("MDD_DIST_BACKEND", "nccl")     # "gloo": rehearsal with every rank on --device (one-GPU box)
         if engine_factory is not None:
             eng = engine_factory(local_rank)
@@ -169,9 +169,7 @@ def run(args, engine_factory=None) -> dict:
         sigs, all_ids, cand_ids, any_synth = [], [], [], False
 
         def padded(text):
-            buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-            buf[: text.size] = text
-            return eng.to_device(buf)
+            return to_padded_device(eng, text)
 
         for r in parsed:
             ids, cand = r["ids"], r["cand"]
@@ -264,8 +262,9 @@ def run(args, engine_factory=None) -> dict:
                 f.write(json.dumps({"doc_id": d, "cluster": rep[l]}, ensure_ascii=False) + "\n")
         with open(os.path.join(args.output_dir, "removed_ids.txt" + suffix), "w", encoding="utf8") as fr, \
                 open(os.path.join(args.output_dir, "kept_ids.txt" + suffix), "w", encoding="utf8") as fk:
-            for d in all_ids:
-                (fr if d in remove_ids else fk).write(f"{d}\n")
+            gone = [d in remove_ids for d in all_ids]
+            fr.write("".join(f"{d}\n" for d, g in zip(all_ids, gone) if g))      # (one write per list, not one per id)
+            fk.write("".join(f"{d}\n" for d, g in zip(all_ids, gone) if not g))
         kept_rows = None
         if args.write_shards:
             os.makedirs(os.path.join(args.output_dir, "shards"), exist_ok=True)

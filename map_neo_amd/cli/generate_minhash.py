@@ -35,7 +35,7 @@ def build_parser():
 
 def process_dir(args):
     from .. import hostio
-    from ..minhash import Engine, as_u32, padded_size
+    from ..minhash import Engine, as_u32, to_padded_device
     eng = Engine(args.device)
     os.makedirs(args.output_dir, exist_ok=True)
     for band in range(args.bands):
@@ -53,9 +53,7 @@ def process_dir(args):
                     yield fi, line_no[m], sig[m]
         else:
             for fi, line_no, text, offs in Z.iter_shards(files, args.content_field_name, min(16, args.workers)):
-                buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-                buf[: text.size] = text
-                sig = as_u32(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width, args.ngram_unit,
+                sig = as_u32(eng.signatures(to_padded_device(eng, text), eng.to_device(offs), args.num_perm, args.width, args.ngram_unit,
                                             args.seed, text_bytes=int(text.size)))
                 yield fi, line_no, sig.reshape(len(line_no), args.num_perm)
 

@@ -163,7 +163,7 @@ def minhashLsh(args) -> dict:
     try:
         import torch
 
-        from ..minhash import Engine, as_u32, padded_size
+        from ..minhash import Engine, as_u32, to_padded_device
         sig_h = edges = labels = None
         if resume:
             state = ckpt.load(args.inter_dir, resume, params, args.input_dir)
@@ -183,13 +183,12 @@ def minhashLsh(args) -> dict:
             for path, ids, cand, text, offs in parsed:
                 n_rows += len(ids)
                 if len(cand):
-                    buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-                    buf[: text.size] = text
+                    buf = to_padded_device(eng, text)
                     if host_norm:
-                        sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                        sigs.append(eng.signatures(buf, eng.to_device(offs), args.num_perm, args.width,
                                                    args.ngram_unit, args.seed, text_bytes=int(text.size)))
                     else:
-                        s, nh = eng.signatures_en(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+                        s, nh = eng.signatures_en(buf, eng.to_device(offs), args.num_perm, args.width,
                                                   args.ngram_unit, args.seed)
                         sigs.append(s)
                         n_host_docs += nh

@@ -63,7 +63,7 @@ def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 
     whose lines can be copied as byte ranges (copy_without_lines)."""
     from concurrent.futures import ThreadPoolExecutor
 
-    from ..minhash import padded_size
+    from ..minhash import to_padded_device
     workers = max(1, int(workers or 1))
     batches, cur, size = [], [], 0
     for k, p in enumerate(files):
@@ -78,9 +78,7 @@ def iter_shards_device(eng, files, field: str, workers: int, batch_bytes: int = 
 
     def host_route(k):
         line_no, text, offs = read_jsonl_texts(files[k], field)
-        buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-        buf[: text.size] = text
-        return (np.full(len(line_no), k, dtype=np.int64), line_no, eng.to_device(buf), eng.to_device(np.ascontiguousarray(offs)),
+        return (np.full(len(line_no), k, dtype=np.int64), line_no, to_padded_device(eng, text), eng.to_device(np.ascontiguousarray(offs)),
                 int(text.size))
 
     # Two producer threads, each with a stream and a context of its own, take the batches in turn: read (threads of

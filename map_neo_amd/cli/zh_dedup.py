@@ -56,7 +56,7 @@ class _Ids:
 def run(args):
     from .. import hostio
     from ..dedup import cluster_local
-    from ..minhash import Engine, as_u32, padded_size
+    from ..minhash import Engine, as_u32, to_padded_device
     files = hostio.list_files(args.input_dir)
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -91,9 +91,7 @@ def run(args):
                 continue
             file_of.append(np.full(len(line_no), fi, dtype=np.int64))
             line_of.append(line_no.astype(np.int64))
-            buf = np.zeros(padded_size(text.size), dtype=np.uint8)
-            buf[: text.size] = text
-            sigs.append(eng.signatures(eng.to_device(buf), eng.to_device(offs), args.num_perm, args.width,
+            sigs.append(eng.signatures(to_padded_device(eng, text), eng.to_device(offs), args.num_perm, args.width,
                                        args.ngram_unit, args.seed, text_bytes=int(text.size)))
     if eng is None:
         eng = Engine(args.device)

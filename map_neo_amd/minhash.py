@@ -59,6 +59,27 @@ def pack_texts(texts: Iterable) -> Tuple[np.ndarray, np.ndarray]:
     return buf, offs
 
 
+def to_padded_device(eng, text: np.ndarray):
+    """The packed text of a shard (host uint8 array) as the device buffer mdd_signatures wants: MDD_TEXT_PAD zero bytes
+    behind it, 4-byte rounded.  On a GPU engine the padding is made on the device and the bytes are copied once -- a padded
+    HOST copy first (np.zeros + assignment) was ~40 ms per 136 MB shard on the thread that feeds the GPU.  Other engines
+    (the CPU backend of the tests) get the padded host array through their own to_device."""
+    n = int(text.size)
+    dev = getattr(eng, "device", None)
+    if not isinstance(dev, torch.device) or dev.type != "cuda":
+        buf = np.zeros(padded_size(n), dtype=np.uint8)
+        buf[:n] = text
+        return eng.to_device(buf)
+    out = torch.zeros(padded_size(n), dtype=torch.uint8, device=dev)
+    if n:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)      # Arrow / frombuffer arrays are read-only: they are only read here
+            src = torch.from_numpy(np.ascontiguousarray(text).view(np.uint8).reshape(-1))
+        out[:n].copy_(src)
+    return out
+
+
 def make_perms(seed: int = SEED, num_perm: int = NUM_PERM) -> Tuple[np.ndarray, np.ndarray]:
     """Permutation table (datasketch _init_permutations, called per doc at EN:62 / ZH-1:28)
     computed once by libmdd_hip's own MT19937 (host code; needs no GPU)."""
