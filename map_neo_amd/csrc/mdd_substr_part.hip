@@ -1504,6 +1504,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
             }
             L.next[idx] = (uint16_t)(old & RS_NIL);
         };
+        uint32_t n_mem = 0;  // BIG: members of the round
         if constexpr (!BIG) {
             unsigned long long e[RS_CH];
 #pragma unroll
@@ -1521,19 +1522,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
                 insert(val, k * 64 + lane);
             }
         } else {
-            uint32_t n_mem = 0;
+            // the round's anchors are a share of the leaf: they are queued (lval / lidx are free until step 2) and inserted 64
+            // at a time, so the probe loops run with every lane busy (inserting straight from the leaf's chunks left half of
+            // them idle: 276 ms for the 2.66 G anchors of a C4-sized shard)
+            uint32_t n_q = 0;
+            auto flush = [&](uint32_t cnt) {  // the first cnt <= 64 queued anchors become members n_mem ..
+                lds_sync();
+                const uint32_t idx = n_mem + lane;
+                if (lane < cnt && idx < RS_MAX) {
+                    L.midx[idx] = L.lidx[lane];
+                    insert(L.lval[lane], idx);
+                }
+                n_mem += cnt;
+            };
             for (uint64_t c0 = lo; c0 < hi; c0 += 64) {
                 const uint64_t i = c0 + lane;
                 const unsigned long long val = i < hi ? A.ent[i] : ENT_INVALID;
                 const bool take = val != ENT_INVALID && mine(val, round);
                 const uint64_t tb = __ballot(take);
-                const uint32_t idx = n_mem + below(tb);
-                if (take && idx < RS_MAX) {
-                    L.midx[idx] = (uint16_t)(i - lo);
-                    insert(val, idx);
+                if (take) {
+                    const uint32_t at = n_q + below(tb);
+                    L.lval[at] = val;
+                    L.lidx[at] = (uint16_t)(i - lo);
                 }
-                n_mem += (uint32_t)__popcll(tb);
+                n_q += (uint32_t)__popcll(tb);
+                if (n_q >= 64) {
+                    flush(64);
+                    const uint32_t rest = n_q - 64;
+                    unsigned long long v = 0;
+                    uint16_t ix = 0;
+                    if (lane < rest) v = L.lval[64 + lane], ix = L.lidx[64 + lane];
+                    lds_sync();
+                    if (lane < rest) L.lval[lane] = v, L.lidx[lane] = ix;
+                    n_q = rest;
+                }
             }
+            if (n_q) flush(n_q);
             if (n_mem > RS_MAX) {  // more than the table takes in one share (it holds 320 on average): the window sort's business
                 for (uint64_t i = lo + lane; i < hi; i += 64) {
                     const unsigned long long val = A.ent[i];
@@ -1634,27 +1658,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
             lds_sync();
             n_list = rest;
         };
-        uint32_t n_seen = 0;  // BIG: members of the round met so far (the numbering of step 1)
-        for (uint64_t c0 = lo; c0 < hi; c0 += 64) {
+        // (BIG: the round's members one after the other, through midx -- every lane has one)
+        const uint64_t n_walk = BIG ? (uint64_t)n_mem : hi - lo;
+        for (uint64_t c0 = 0; c0 < n_walk; c0 += 64) {
             const uint64_t i = c0 + lane;
-            bool work = false, take = false;
+            bool work = false;
             unsigned long long val = ENT_INVALID;
             uint32_t slot = 0;
-            if (i < hi) {
-                val = A.ent[i];  // (second read: from the L2)
-                take = val != ENT_INVALID && mine(val, round);
-                if (take) {
-                    slot = find_slot(val);
-                    work = L.tab[slot] != val;  // not the group's lowest anchor (a lone anchor is its group's lowest)
-                }
+            if (i < n_walk) {
+                val = A.ent[lo + (BIG ? (uint64_t)L.midx[i] : i)];  // (second read: from the L2)
+                slot = find_slot(val);
+                work = L.tab[slot] != val;  // not the group's lowest anchor (a lone anchor is its group's lowest)
             }
             const uint64_t wb = __ballot(work);
-            uint32_t member = (uint32_t)(i - lo);
-            if constexpr (BIG) {
-                const uint64_t tb = __ballot(take);
-                member = n_seen + below(tb);
-                n_seen += (uint32_t)__popcll(tb);
-            }
+            const uint32_t member = (uint32_t)i;
             if (work) {
                 const uint32_t at = n_list + below(wb);
                 L.lval[at] = val;
@@ -1669,9 +1686,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
         bool any_fb = false;
         if (lane < RS_SLOTS / 32) any_fb = L.fb[lane] != 0u;
         if (__ballot(any_fb)) {
-            for (uint64_t i = lo + lane; i < hi; i += 64) {
-                const unsigned long long val = A.ent[i];
-                if (val == ENT_INVALID || !mine(val, round)) continue;
+            for (uint64_t i = lane; i < n_walk; i += 64) {
+                const unsigned long long val = A.ent[lo + (BIG ? (uint64_t)L.midx[i] : i)];
                 const uint32_t slot = find_slot(val);
                 const uint64_t pos = val & POS_M;
                 if (((L.fb[slot >> 5] >> (slot & 31u)) & 1u) && pos < A.text_bytes) A.flag[pos] = 1;
