@@ -166,39 +166,42 @@ def copy_without_lines(src: str, dst: str, drop, line_starts=None) -> None:
     runs (os.writev straight from the mapping: page cache to page cache, no Python-level copy, no call per run;
     tools/zh5_write_probe.py: twice the rate of a copy_file_range per run, whose unaligned ranges go through a pipe)."""
     if line_starts is not None and hasattr(os, "writev"):
-        n_lines = len(line_starts) - 1
-        ls = np.asarray(line_starts, dtype=np.int64)
-        cuts = np.asarray(sorted(x for x in drop if 0 <= x < n_lines), dtype=np.int64)
-        lo = np.concatenate(([0], ls[cuts + 1]))              # kept runs [lo, hi): between dropped lines
-        hi = np.concatenate((ls[cuts], [ls[-1]]))
-        keep = hi > lo
-        fd = os.open(dst, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:
-            if int(ls[-1]) > 0 and keep.any():
-                with open(src, "rb") as fi:
-                    m = mmap.mmap(fi.fileno(), 0, prot=mmap.PROT_READ)
-                mv = memoryview(m)
-                try:
-                    iov = [mv[a:b] for a, b in zip(lo[keep].tolist(), hi[keep].tolist())]
-                    for i in range(0, len(iov), 1024):          # IOV_MAX
-                        chunk = iov[i:i + 1024]
-                        want, got = sum(len(x) for x in chunk), os.writev(fd, chunk)
-                        if got < want:                          # short write: the rest of the chunk piece by piece
-                            for x in chunk:
-                                if got >= len(x):
-                                    got -= len(x)
-                                    continue
-                                x = x[got:]
-                                got = 0
-                                while len(x):
-                                    x = x[os.write(fd, x):]
-                finally:
-                    iov = chunk = x = None
-                    mv.release()
-                    m.close()
-        finally:
-            os.close(fd)
-        return
+            n_lines = len(line_starts) - 1
+            ls = np.asarray(line_starts, dtype=np.int64)
+            cuts = np.asarray(sorted(x for x in drop if 0 <= x < n_lines), dtype=np.int64)
+            lo = np.concatenate(([0], ls[cuts + 1]))              # kept runs [lo, hi): between dropped lines
+            hi = np.concatenate((ls[cuts], [ls[-1]]))
+            keep = hi > lo
+            fd = os.open(dst, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            try:
+                if int(ls[-1]) > 0 and keep.any():
+                    with open(src, "rb") as fi:
+                        m = mmap.mmap(fi.fileno(), 0, prot=mmap.PROT_READ)
+                    mv = memoryview(m)
+                    try:
+                        iov = [mv[a:b] for a, b in zip(lo[keep].tolist(), hi[keep].tolist())]
+                        for i in range(0, len(iov), 1024):          # IOV_MAX
+                            chunk = iov[i:i + 1024]
+                            want, got = sum(len(x) for x in chunk), os.writev(fd, chunk)
+                            if got < want:                          # short write: the rest of the chunk piece by piece
+                                for x in chunk:
+                                    if got >= len(x):
+                                        got -= len(x)
+                                        continue
+                                    x = x[got:]
+                                    got = 0
+                                    while len(x):
+                                        x = x[os.write(fd, x):]
+                    finally:
+                        iov = chunk = x = None
+                        mv.release()
+                        m.close()
+            finally:
+                os.close(fd)
+            return
+        except (OSError, ValueError):      # a source that cannot be mapped (a pipe, a special file): the byte route below
+            pass
     with open(src, "rb") as f:
         data = f.read()
     # The reference reads plain text only (ZH-1:40, ZH-5:9); the ingest of these commands also accepts gzip'd shards and
