@@ -1240,17 +1240,19 @@ __global__ void __launch_bounds__(64) anchor_leaf_kernel(const uint64_t* __restr
 }
 
 // ---- resolving repeated anchors on the spot (window == 50) ----------------------------------------------------------
-// vmap[p] = 1 when a window of `window` code points that the stage hashes starts at byte p: p is a code-point start of its
+// vmap bit p = 1 when a window of `window` code points that the stage hashes starts at byte p: p is a code-point start of its
 // document and more than `window` code points start at or after it (SUB:38 range(len(text) - duplicate_len)).  One wave per
 // document: count the code points (and see whether there is a byte >= 0x80 at all), then write -- pure-ASCII documents are
-// not read a second time.  Dword stores inside the document, byte stores where a dword is shared with a neighbour.
+// not read a second time.  A BITMAP (bit p & 31 of word p >> 5; cleared by the caller): an eighth of the bytes to write, and
+// what anchor_resolve_kernel reads of it -- 19 bits per region, scattered -- stays in the caches (272 MB for C2 instead of
+// 2.2 GB).  A lane holds the 4 bits of its dword; the lanes of one word combine theirs (three shuffles) and the first of
+// them stores the word, with an atomic OR where the word is shared with another document or another step.
 __global__ void __launch_bounds__(256) vmap_kernel(const uint8_t* __restrict__ text, uint64_t text_bytes, const uint64_t* __restrict__ offs,
-                                                   uint64_t n, uint32_t window, uint8_t* __restrict__ vmap) {
+                                                   uint64_t n, uint32_t window, uint32_t* __restrict__ vmap) {
     const uint32_t lane = lane_id();
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(text);
-    uint32_t* __restrict__ vw = reinterpret_cast<uint32_t*>(vmap);
     for (uint64_t d = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n; d += nw) {
         uint64_t b, e;
         doc_range(offs, d, text_bytes, b, e);
@@ -1266,13 +1268,22 @@ __global__ void __launch_bounds__(256) vmap_kernel(const uint8_t* __restrict__ t
             }
             return in;
         };
-        auto put = [&](uint64_t i, uint32_t in, uint32_t v) {  // v: 0 / 1 per byte
-            if (in == 0x80808080u && (i + 1) * 4 <= text_bytes) {
-                vw[i] = v;
-            } else {
+        // every lane of the wave calls it (i = first dword of the step + lane); v: bit k = byte k of dword i starts a hashed window
+        auto put = [&](uint64_t i, bool live, uint32_t in, uint32_t v) {
+            uint32_t val = live ? (v & 0xFu) << (4u * (uint32_t)(i & 7u)) : 0u;
+            bool whole = live && in == 0x80808080u;  // the lane's dword lies inside the document
+            const uint64_t word = i >> 3;
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if ((in & (0x80u << (8 * k))) && i * 4 + k < text_bytes) vmap[i * 4 + k] = (uint8_t)(v >> (8 * k));
+            for (uint32_t sft = 1; sft <= 4; sft <<= 1) {  // OR over the lanes of the same word (consecutive lanes)
+                const uint32_t ov = (uint32_t)__shfl_down((int)val, sft, 64);
+                const int ow = __shfl_down((int)whole, sft, 64);
+                if (lane + sft < 64u && ((i + sft) >> 3) == word) val |= ov, whole = whole && ow;
+            }
+            const bool first = live && (lane == 0u || (i & 7u) == 0u);  // the word's first lane in this step
+            if (first) {
+                // all 8 dwords of the word in this step and inside the document: nobody else writes the word
+                if ((i & 7u) == 0u && lane + 7u < 64u && whole) vmap[word] = val;
+                else if (val) atomicOr(&vmap[word], val);
             }
         };
         uint32_t cnt = 0, hi_bits = 0;
@@ -1299,13 +1310,20 @@ __global__ void __launch_bounds__(256) vmap_kernel(const uint8_t* __restrict__ t
         const uint64_t ncp = cnt;  // code points of the document; window c (0-based code point index) is hashed iff c + window < ncp
         if (ascii) {
             const uint64_t nv = ncp > window ? ncp - window : 0;  // valid starts: bytes b .. b + nv - 1
-            for (uint64_t i = w0 + lane; i < w1; i += 64) {
-                const uint32_t in = inside(i);
-                uint32_t v = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (i * 4 + k >= b && i * 4 + k < b + nv) v |= 1u << (8 * k);
-                put(i, in, v);
+            // the valid starts are the bytes [b, b + nv): a lane writes a whole word of the map (32 positions) from the range alone
+            const uint64_t v_end = b + nv;
+            for (uint64_t wj = (b >> 5) + lane; wj <= ((e - 1) >> 5); wj += 64) {
+                const uint64_t lo = wj << 5;
+                uint32_t m = 0;
+                if (v_end > lo && b < lo + 32) {
+                    const uint32_t s0 = b > lo ? (uint32_t)(b - lo) : 0u;
+                    const uint32_t t0 = v_end < lo + 32 ? (uint32_t)(v_end - lo) : 32u;  // exclusive
+                    if (t0 > s0) m = (t0 - s0 == 32u) ? 0xFFFFFFFFu : (((1u << (t0 - s0)) - 1u) << s0);
+                }
+                if (m) {
+                    if (lo >= b && lo + 32 <= e) vmap[wj] = m;  // the word's 32 positions all belong to this document
+                    else atomicOr(&vmap[wj], m);
+                }
             }
         } else {
             uint64_t done = 0;  // code points that start before this step
@@ -1321,10 +1339,10 @@ __global__ void __launch_bounds__(256) vmap_kernel(const uint8_t* __restrict__ t
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (S & (0x80u << (8 * k))) {
-                        if (idx + window < ncp) v |= 1u << (8 * k);
+                        if (idx + window < ncp) v |= 1u << k;
                         idx++;
                     }
-                if (i < w1) put(i, in, v);
+                put(i, i < w1, in, v);
                 done += __builtin_popcountll(B0) + 2 * __builtin_popcountll(B1) + 4 * __builtin_popcountll(B2);
             }
         }
@@ -1378,7 +1396,7 @@ struct ResolveArgs {
     uint32_t n_leaves;
     const uint8_t* text;
     uint64_t text_bytes;
-    const uint8_t* vmap;
+    const uint32_t* vmap;  // bitmap of hashed window starts (vmap_kernel)
     uint8_t* dup;
     uint8_t* flag;
     uint32_t max_group;  // RS_GROUP (a tuning knob lowers / raises it: MDD_SUBSTR_GROUP)
@@ -1389,21 +1407,11 @@ struct ResolveArgs {
 };
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
-// bit u of the result: byte u of the 19 bytes at p is non-zero (vmap bytes are 0 / 1)
-__device__ __forceinline__ uint32_t vmask19(const uint8_t* vmap, uint64_t p) {
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(vmap) + (p >> 2);
-    const uint32_t sh = (uint32_t)p & 3u;
-    uint32_t r[6];
-    const u32x4_a4 v0 = *reinterpret_cast<const u32x4_a4*>(q);
-    const u32x2_a4 v1 = *reinterpret_cast<const u32x2_a4*>(q + 4);
-    r[0] = v0.x, r[1] = v0.y, r[2] = v0.z, r[3] = v0.w, r[4] = v1.x, r[5] = v1.y;
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const uint32_t w = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & 0x01010101u;
-        m |= ((w * 0x01020408u) >> 24) << (4 * k);  // bytes 0..3 -> bits 0..3
-    }
-    return m & 0x7FFFFu;
+// bit u of the result: bit p + u of the bitmap, u < 19
+__device__ __forceinline__ uint32_t vmask19(const uint32_t* vmap, uint64_t p) {
+    const u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(vmap + (p >> 5));
+    const uint64_t x = ((uint64_t)v.y << 32) | v.x;
+    return (uint32_t)(x >> (p & 31u)) & 0x7FFFFu;
 }
 
 // region of an anchor at a: the 72 bytes from a - 20 as 18 dwords
@@ -1857,11 +1865,12 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));
     const bool resolve = window == (int)AN_MINWIN;  // repeated anchors are settled in their leaves (anchor_resolve_kernel)
     if (resolve) {
-        // cand holds the map of hashed window starts until smear_kernel overwrites it (bytes outside every document: 0)
-        HIP_TRY(hipMemsetAsync(cand, 0, text_bytes, st));
+        // the start of cand holds the bitmap of hashed window starts (text_bytes / 8 bytes + the two words a 19-bit read may
+        // reach past them) until smear_kernel overwrites cand
+        HIP_TRY(hipMemsetAsync(cand, 0, (text_bytes / 32 + 3) * 4 < text_bytes ? (text_bytes / 32 + 3) * 4 : text_bytes, st));
         uint64_t blocks = (n_docs + 3) / 4, cap = (uint64_t)ctx->cus * 64;
         hipLaunchKernelGGL(vmap_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, st, text, text_bytes, offsets, n_docs,
-                           (uint32_t)window, cand);
+                           (uint32_t)window, reinterpret_cast<uint32_t*>(cand));
         HIP_TRY(hipGetLastError());
     }
     AnchorArgs E{};
@@ -1903,7 +1912,7 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
         R.n_leaves = n_leaves_a;
         R.text = text;
         R.text_bytes = text_bytes;
-        R.vmap = cand;
+        R.vmap = reinterpret_cast<const uint32_t*>(cand);
         R.dup = dup;
         R.flag = flag;
         R.max_group = RS_GROUP;
