@@ -346,8 +346,9 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          part / n_parts as for `mark` (windows are split by content key; part 0 clears dup).  An entry array that is
  *          too small, or more than 768 distinct windows in one leaf (or one 4096-window slice of a big leaf), is
  *          counted and reported by mdd_substr_check: redo with more parts, or use `mark`.
- *          cand (round 3; NULL = every window takes part): u8[text_bytes] from mdd_substr_candidates -- windows whose
- *          flag is 0 are skipped.  The marks are the same with and without it; ent_cap then only has to hold the
+ *          cand (round 3; NULL = every window takes part): the bitmap mdd_substr_candidates made (bit p & 63 of u64 word
+ *          p >> 6 = byte position p; MDD_SUBSTR_CAND_BYTES(text_bytes) bytes, 8-byte aligned) -- windows whose bit is 0
+ *          are skipped.  The marks are the same with and without it; ent_cap then only has to hold the
  *          candidate windows of the pass; dup is NOT cleared by part 0 then (mdd_substr_candidates has cleared it and,
  *          for window = 50, already holds marks).
  *   candidates: the filter in front of mark_sorted (same reference lines: it decides nothing, it only proves windows
@@ -356,8 +357,8 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          those starting in its first 19 bytes, leftmost on ties -- occurs twice in the corpus.  The selected k-grams
  *          ("anchors", one per ~10 windows) are sorted and grouped like windows (same workspaces; ent_cap >=
  *          max(windows / 6, (text_bytes + 71) / 8) + the slack above is ample: anchors beyond it switch the filter
- *          off, they do not fail the call), and cand[p] = 1 for every byte position p with a repeated anchor in
- *          [p, p + 18].  *n_cand (DEVICE) = number of flagged positions, an upper bound of the windows mark_sorted
+ *          off, they do not fail the call), and bit p of cand is set for every byte position p with a repeated anchor in
+ *          [p, p + 18] (cand: MDD_SUBSTR_CAND_BYTES(text_bytes) bytes; the call also uses it as scratch).  *n_cand (DEVICE) = number of flagged positions, an upper bound of the windows mark_sorted
  *          will sort.  Asynchronous.  50 <= window <= 128 (a window of w code points has >= w bytes; below 50 bytes
  *          the selection does not fit: call mark_sorted with cand = NULL); cand 8-byte aligned.
  *          dup: u8[text_bytes], cleared here.  For window = 50 the repeated anchors are settled on the spot: the 68 bytes
@@ -371,6 +372,7 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          windows remain for mark_sorted and the stage takes 29.5 instead of 79 ms (filter alone, window != 50: 28 %
  *          remain, 61 ms). */
 #define MDD_SUBSTR_SORTED_WS_WORDS 11672587ull
+#define MDD_SUBSTR_CAND_BYTES(text_bytes) ((((uint64_t)(text_bytes) >> 6) + 2) * 8) /* candidate bitmap: a bit per text byte + a spare word */
 int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, const uint64_t* offsets, uint64_t n_docs,
                            int window, int part, int n_parts, uint64_t* ent_a, uint64_t* ent_b, uint64_t ent_cap,
                            uint16_t* d1_ws, uint64_t* ws, uint64_t ws_words, uint8_t* dup, const uint8_t* cand);

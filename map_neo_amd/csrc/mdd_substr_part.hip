@@ -129,18 +129,18 @@ struct EmitArgs {
     unsigned long long* overflow;
     uint32_t part, n_parts;
     uint32_t batch_shift;  // a claim on the work counter takes (items left) >> batch_shift items, clamped to [1, 16]
-    const uint8_t* cand;   // candidate flag per byte position (mdd_substr_candidates) or NULL: every window takes part
+    const uint64_t* cand;  // candidate bitmap, a bit per byte position (mdd_substr_candidates), or NULL: every window takes part
     uint32_t max_batch;    // items per claim at most (16 without the filter; with it an item is cheap and batches of 64 keep the claims rare)
 };
 
 // persistent waves pulling documents (then queued segments of long documents) from one counter, four waves per workgroup
 // sharing the LDS histogram of d1; every wave leaves once the counter passes `total`
 constexpr int EMIT_WAVES = 4;
-constexpr int CPLANE_BLOCKS = 66;  // candidate-flag bit planes per wave: 66 blocks of 64 dwords = a 16 KiB segment + alignment
+constexpr int CPLANE_WORDS = 264;  // candidate bits per wave in LDS: 264 x 64 positions = a 16 KiB segment + alignment
 __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
     __shared__ WaveLds lds_all[EMIT_WAVES];
     __shared__ unsigned int h1[BINS1];
-    __shared__ uint64_t cplane_all[EMIT_WAVES][CPLANE_BLOCKS * 4];
+    __shared__ uint64_t cplane_all[EMIT_WAVES][CPLANE_WORDS];
     WaveLds& lds = lds_all[threadIdx.x >> 6];
     uint64_t* cplane = cplane_all[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
@@ -180,54 +180,31 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
         const bool split = len > A.seg_bytes;
         const uint32_t seg_beg = seg * A.seg_bytes;
         const uint32_t seg_end = (uint64_t)seg_beg + A.seg_bytes < len ? seg_beg + A.seg_bytes : len;
-        // With the candidate filter few windows are left and a round of 64 windows would wait a memory round trip for its 64
-        // flag bytes only to find none set.  So the item's flags are read ONCE (a dword per lane, all loads in flight) into
-        // bit planes in LDS: plane j of block k = ballot over the 64 dwords of block k of "byte j is set".  A window then
-        // finds its flag with one LDS read, and an item without any candidate is dropped before its text is touched.
-        uint64_t plane_dw0 = 0;   // dword index (of the flag array) of block 0
+        // With the candidate filter few windows are left and a round of 64 windows would wait a memory round trip for its
+        // flags only to find none set.  So the item's words of the candidate bitmap are read ONCE into LDS (all loads in
+        // flight): a window then finds its flag with one LDS read, and an item without any candidate is dropped before its
+        // text is touched.
+        uint64_t plane_u0 = 0;    // index (in the bitmap) of the first word held in LDS
         bool planes = false;
         if (A.cand) {
             const uint64_t p0 = beg + seg_beg, p1 = beg + seg_end;  // window starts of this item lie in [p0, p1)
             if (p0 >= p1) continue;
-            const uint32_t* cw = reinterpret_cast<const uint32_t*>(A.cand);
-            const uint64_t full = A.text_bytes >> 2;  // dwords that lie inside the flag array
-            const uint64_t d0 = p0 >> 2, d1 = (p1 - 1) >> 2;
-            auto flags_of = [&](uint64_t i) -> uint32_t {
-                uint32_t v = 0;
-                if (i <= d1) {
-                    if (i < full) v = cw[i];
-                    else
-                        for (uint64_t q = i * 4; q < A.text_bytes; q++) v |= (uint32_t)A.cand[q] << (8 * (q - i * 4));
-                }
-                return v;
-            };
-            bool any = false;
-            if (d1 - d0 < (uint64_t)CPLANE_BLOCKS * 64) {
+            const uint64_t u0 = p0 >> 6, u1 = (p1 - 1) >> 6;
+            uint64_t acc = 0;
+            if (u1 - u0 < (uint64_t)CPLANE_WORDS) {
                 planes = true;
-                plane_dw0 = d0;
+                plane_u0 = u0;
                 lds_sync();  // (the previous item's readers are done)
-                for (uint64_t blk = 0; d0 + blk * 64 <= d1; blk += 4) {
-                    uint32_t v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] = flags_of(d0 + (blk + u) * 64 + lane);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (d0 + (blk + u) * 64 > d1) break;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint64_t B = __ballot(((v[u] >> (8 * j)) & 0xFFu) != 0u);
-                            any = any || B != 0;
-                            if (lane == 0) cplane[(blk + u) * 4 + j] = B;
-                        }
-                    }
+                for (uint64_t i = lane; u0 + i <= u1; i += 64) {
+                    const uint64_t v = A.cand[u0 + i];
+                    cplane[i] = v;
+                    acc |= v;
                 }
                 lds_sync();
-            } else {  // a segment beyond the planes (segments grow with texts beyond 16 GiB): flags straight from memory
-                uint32_t acc = 0;
-                for (uint64_t i = d0 + lane; i <= d1; i += 64) acc |= flags_of(i);
-                any = __ballot(acc != 0u) != 0ull;
+            } else {  // a segment beyond the LDS words (segments grow with texts beyond 16 GiB): flags straight from memory
+                for (uint64_t i = u0 + lane; i <= u1; i += 64) acc |= A.cand[i];
             }
-            if (!any) continue;
+            if (!__ballot(acc != 0ull)) continue;  // (bits of the neighbours in the first and last word only cost a look)
         }
         TextView tv;
         tv.docw = tw + (beg >> 2);
@@ -282,20 +259,17 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                 q_head += n;
                 lds_sync();
             };
-            const uint64_t d1 = (beg + seg_end - 1) >> 2;
-            for (uint64_t blk = 0; plane_dw0 + blk * 64 <= d1; blk++) {
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint64_t B = cplane[blk * 4 + j];
-                    if (B == 0) continue;
-                    const uint64_t q = (plane_dw0 + blk * 64 + lane) * 4 + j;  // absolute position of this lane's bit
-                    const bool sel = ((B >> lane) & 1ull) && q >= beg + seg_beg && q < beg + sb_end;
-                    const uint64_t sbal = __ballot(sel);
-                    if (sbal == 0) continue;
-                    if (sel) lds.ringS[(q_tail + below(sbal)) & (RING - 1)] = (uint32_t)(q - beg);
-                    q_tail += (uint32_t)__popcll(sbal);
-                    if (q_tail - q_head >= 64u) hash_queued(64u);
-                }
+            const uint64_t u1 = (beg + seg_end - 1) >> 6;
+            for (uint64_t wd = 0; plane_u0 + wd <= u1; wd++) {
+                const uint64_t B = cplane[wd];
+                if (B == 0) continue;
+                const uint64_t q = ((plane_u0 + wd) << 6) + lane;  // absolute position of this lane's bit
+                const bool sel = ((B >> lane) & 1ull) && q >= beg + seg_beg && q < beg + sb_end;
+                const uint64_t sbal = __ballot(sel);
+                if (sbal == 0) continue;
+                if (sel) lds.ringS[(q_tail + below(sbal)) & (RING - 1)] = (uint32_t)(q - beg);
+                q_tail += (uint32_t)__popcll(sbal);
+                if (q_tail - q_head >= 64u) hash_queued(64u);
             }
             if (q_tail != q_head) hash_queued(q_tail - q_head);
             continue;
@@ -308,12 +282,8 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) emit_kernel(EmitArgs A) {
                            // candidate filter: a window whose selected k-gram occurs once in the corpus occurs once itself
                            if (A.cand && on) {
                                const uint64_t q = beg + sb;
-                               if (planes) {
-                                   const uint64_t dwi = (q >> 2) - plane_dw0;
-                                   on = (cplane[(dwi >> 6) * 4 + (q & 3u)] >> (dwi & 63u)) & 1ull;
-                               } else {
-                                   on = A.cand[q] != 0;
-                               }
+                               const uint64_t wq = planes ? cplane[(q >> 6) - plane_u0] : A.cand[q >> 6];
+                               on = (wq >> (q & 63u)) & 1ull;
                            }
                            uint64_t key = 0;
                            if (on) {
@@ -1189,11 +1159,15 @@ __global__ void __launch_bounds__(64 * EMIT_WAVES) anchor_kernel(AnchorArgs A) {
         if (h1[i]) atomicAdd(&A.hist1[i], h1[i]);
 }
 
+// the anchor flags are a bitmap (a bit per text position; cleared by the caller): 272 MB for C2 instead of 2.2 GB to clear,
+// to scatter into and to stream through smear_kernel
+__device__ __forceinline__ void set_flag(uint32_t* flag, uint64_t pos) { atomicOr(&flag[pos >> 5], 1u << (pos & 31u)); }
+
 // One wave per leaf of anchors: flag every anchor whose (d2, tag) occurs twice in the leaf.  Key equality only -- a false
 // match lets a few windows through, nothing else -- so a leaf too big for the table is flagged whole.
 constexpr uint32_t ALEAF_CH = 12;  // 768 anchors per leaf at most go through the table (1024 slots)
 __global__ void __launch_bounds__(64) anchor_leaf_kernel(const uint64_t* __restrict__ ent, const uint64_t* __restrict__ off2, uint32_t n_leaves,
-                                                         uint8_t* flag, uint64_t text_bytes) {
+                                                         uint32_t* flag, uint64_t text_bytes) {
     __shared__ unsigned long long tab[LEAF_SLOTS];
     const uint32_t lane = lane_id();
     for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
@@ -1202,7 +1176,7 @@ __global__ void __launch_bounds__(64) anchor_leaf_kernel(const uint64_t* __restr
         if (hi - lo > 64 * ALEAF_CH) {
             for (uint64_t i = lo + lane; i < hi; i += 64) {
                 const uint64_t pos = ent[i] & POS_M;
-                if (pos < text_bytes) flag[pos] = 1;
+                if (pos < text_bytes) set_flag(flag, pos);
             }
             continue;
         }
@@ -1228,8 +1202,8 @@ __global__ void __launch_bounds__(64) anchor_leaf_kernel(const uint64_t* __restr
                 if (cur == ENT_INVALID) break;
                 if ((cur >> POS_BITS) == (val >> POS_BITS)) {
                     const uint64_t p = val & POS_M, q = cur & POS_M;
-                    if (p < text_bytes) flag[p] = 1;
-                    if (q < text_bytes) flag[q] = 1;
+                    if (p < text_bytes) set_flag(flag, p);
+                    if (q < text_bytes) set_flag(flag, q);
                     break;
                 }
                 slot = (slot + 1) & (LEAF_SLOTS - 1);
@@ -1398,7 +1372,7 @@ struct ResolveArgs {
     uint64_t text_bytes;
     const uint32_t* vmap;  // bitmap of hashed window starts (vmap_kernel)
     uint8_t* dup;
-    uint8_t* flag;
+    uint32_t* flag;      // a bit per text position: the anchor there goes to the window sort (set_flag)
     uint32_t max_group;  // RS_GROUP (a tuning knob lowers / raises it: MDD_SUBSTR_GROUP)
     uint32_t big_hi;     // a leaf of RS_MAX + 1 .. big_hi anchors is settled in rounds (anchor_resolve_kernel<true>), a larger one
                          // is flagged whole.  RS_MAX when the leaves are expected to hold ~200 (a leaf above that is heavy repetition,
@@ -1473,7 +1447,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
             if (hi - lo > A.big_hi)                // heavy repetition: the window sort's business
                 for (uint64_t i = lo + lane; i < hi; i += 64) {
                     const uint64_t pos = A.ent[i] & POS_M;
-                    if (pos < A.text_bytes) A.flag[pos] = 1;
+                    if (pos < A.text_bytes) set_flag(A.flag, pos);
                 }
             continue;
         }
@@ -1570,7 +1544,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
                 for (uint64_t i = lo + lane; i < hi; i += 64) {
                     const unsigned long long val = A.ent[i];
                     const uint64_t pos = val & POS_M;
-                    if (val != ENT_INVALID && mine(val, round) && pos < A.text_bytes) A.flag[pos] = 1;
+                    if (val != ENT_INVALID && mine(val, round) && pos < A.text_bytes) set_flag(A.flag, pos);
                 }
                 lds_sync();
                 continue;
@@ -1698,7 +1672,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
                 const unsigned long long val = A.ent[lo + (BIG ? (uint64_t)L.midx[i] : i)];
                 const uint32_t slot = find_slot(val);
                 const uint64_t pos = val & POS_M;
-                if (((L.fb[slot >> 5] >> (slot & 31u)) & 1u) && pos < A.text_bytes) A.flag[pos] = 1;
+                if (((L.fb[slot >> 5] >> (slot & 31u)) & 1u) && pos < A.text_bytes) set_flag(A.flag, pos);
             }
         }
         lds_sync();
@@ -1706,37 +1680,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5)))
     }
 }
 
-// cand[p] = 1 when an anchor in [p, p + 18] is flagged (window p selects one of these positions; flagging all of them is
-// a superset).  8 positions per thread; flag has 32 readable zero bytes past text_bytes.  *overflow != 0 (anchors without
-// room in the entry array): every position is a candidate.  *n_cand += candidate positions.
-__global__ void __launch_bounds__(256) smear_kernel(const uint8_t* __restrict__ flag, uint64_t text_bytes, uint8_t* __restrict__ cand,
+// cand bit p = 1 when an anchor in [p, p + 18] is flagged (window p selects one of these positions; flagging all of them is
+// a superset).  Both are bitmaps: a thread makes 64 positions of cand from 83 bits of flag (OR over 19 shifts by doubling:
+// 1, 2, 4, 8 give 16, one more by 3 gives 19); flag has two readable zero words past the last position.  *overflow != 0
+// (anchors without room in the entry array): every position is a candidate.  *n_cand += candidate positions.
+__global__ void __launch_bounds__(256) smear_kernel(const uint64_t* __restrict__ flag, uint64_t text_bytes, uint64_t* __restrict__ cand,
                                                     unsigned long long* n_cand, const unsigned long long* overflow) {
     __shared__ unsigned int wsum[4];
     const bool all = *overflow != 0;
     uint32_t c = 0;
-    // (grid-stride: one atomic per workgroup at the end -- same-address atomics retire at ~11 ns each, a counter update per
-    // wave of a thread-per-8-bytes launch took 43 ms on 2 GB)
-    for (uint64_t q = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; q < text_bytes; q += (uint64_t)gridDim.x * 2048) {
-        uint64_t out = 0;
-        const uint64_t* f = reinterpret_cast<const uint64_t*>(flag + q);
-        const uint64_t w0 = f[0], w1 = f[1], w2 = f[2], w3 = f[3];
-        if (all) {
-            out = 0x0101010101010101ull;
-        } else if (w0 | w1 | w2 | w3) {
-            // F = w3:w2:w1:w0 (little endian bytes); OR over n consecutive bytes by doubling: r2, r4, r8, r16; 19 = 16 + overlap of r4 at +15
-            auto shr = [](uint64_t lo, uint64_t hi, int bytes) { return (lo >> (8 * bytes)) | (hi << (64 - 8 * bytes)); };  // bytes in 1..7
-            const uint64_t a0 = w0 | shr(w0, w1, 1), a1 = w1 | shr(w1, w2, 1), a2 = w2 | shr(w2, w3, 1), a3 = w3 | (w3 >> 8);   // r2
-            const uint64_t b0 = a0 | shr(a0, a1, 2), b1 = a1 | shr(a1, a2, 2), b2 = a2 | shr(a2, a3, 2);                          // r4 (words 0..2; word 2 lacks bytes >= 32: not needed below byte 26)
-            const uint64_t c0 = b0 | shr(b0, b1, 4), c1 = b1 | shr(b1, b2, 4);                                                    // r8
-            const uint64_t d0 = c0 | c1;                                                                                          // r16 = r8 | r8 >> 64 bits
-            out = d0 | shr(b1, b2, 7);                                                                                            // r4 at byte offset 15
+    const uint64_t n_words = (text_bytes + 63) >> 6;
+    // (grid-stride: one atomic per workgroup at the end -- same-address atomics retire at ~11 ns each)
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * 256) {
+        uint64_t out = ~0ull;
+        if (!all) {
+            uint64_t lo = flag[w], hi = flag[w + 1];
+            out = 0;
+            if (lo | hi) {
+#pragma unroll
+                for (int k = 1; k <= 8; k <<= 1) {  // X |= X >> k on the 128-bit value hi:lo
+                    lo |= (lo >> k) | (hi << (64 - k));
+                    hi |= hi >> k;
+                }
+                out = lo | (lo >> 3) | (hi << 61);
+            }
         }
-        if (q + 8 <= text_bytes) {
-            *reinterpret_cast<uint64_t*>(cand + q) = out;
-        } else {
-            for (uint64_t k = 0; q + k < text_bytes; k++) cand[q + k] = (uint8_t)(out >> (8 * k));
-            out &= ~0ull >> (8 * (8 - (text_bytes - q)));
-        }
+        const uint64_t q = w << 6;
+        if (q + 64 > text_bytes) out &= ~0ull >> (64 - (text_bytes - q));  // (text_bytes - q is 1 .. 63 here)
+        cand[w] = out;
         c += (uint32_t)__builtin_popcountll(out);
     }
 #pragma unroll
@@ -1865,9 +1836,9 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
     HIP_TRY(hipMemsetAsync(dup, 0, text_bytes, st));
     const bool resolve = window == (int)AN_MINWIN;  // repeated anchors are settled in their leaves (anchor_resolve_kernel)
     if (resolve) {
-        // the start of cand holds the bitmap of hashed window starts (text_bytes / 8 bytes + the two words a 19-bit read may
-        // reach past them) until smear_kernel overwrites cand
-        HIP_TRY(hipMemsetAsync(cand, 0, (text_bytes / 32 + 3) * 4 < text_bytes ? (text_bytes / 32 + 3) * 4 : text_bytes, st));
+        // cand holds the bitmap of hashed window starts (the word a 19-bit read may reach past the last position included)
+        // until smear_kernel overwrites it
+        HIP_TRY(hipMemsetAsync(cand, 0, MDD_SUBSTR_CAND_BYTES(text_bytes), st));
         uint64_t blocks = (n_docs + 3) / 4, cap = (uint64_t)ctx->cus * 64;
         hipLaunchKernelGGL(vmap_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, st, text, text_bytes, offsets, n_docs,
                            (uint32_t)window, reinterpret_cast<uint32_t*>(cand));
@@ -1902,8 +1873,8 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
         int rc = sort_into_leaves(st, W, ent_a, ent_b, ent_cap, d1_ws);
         if (rc) return rc;
     }
-    uint8_t* flag = reinterpret_cast<uint8_t*>(ent_b);
-    HIP_TRY(hipMemsetAsync(flag, 0, text_bytes + 64, st));
+    uint32_t* flag = reinterpret_cast<uint32_t*>(ent_b);  // a bit per position + the two zero words smear_kernel reads past them
+    HIP_TRY(hipMemsetAsync(flag, 0, ((text_bytes >> 6) + 3) * 8, st));
     const uint32_t n_leaves_a = (1u << E.d1_bits) * (uint32_t)BINS2;  // anchors carry a 9- to 11-bit level-1 digit
     if (resolve && !getenv("MDD_SUBSTR_NO_RESOLVE")) {     // (the knob: A/B runs and tests of the filter-only path)
         ResolveArgs R{};
@@ -1936,8 +1907,9 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
         hipLaunchKernelGGL(anchor_leaf_kernel, dim3((unsigned)ctx->cus * LEAF_WAVES_PER_CU), dim3(64), 0, st, ent_a, W.off2, n_leaves_a, flag,
                            text_bytes);
     }
-    const uint64_t smear_blocks = (text_bytes + 2047) / 2048, smear_cap = (uint64_t)ctx->cus * 16;
-    hipLaunchKernelGGL(smear_kernel, dim3((unsigned)(smear_blocks < smear_cap ? smear_blocks : smear_cap)), dim3(256), 0, st, flag, text_bytes, cand,
+    const uint64_t smear_blocks = (((text_bytes + 63) >> 6) + 255) / 256, smear_cap = (uint64_t)ctx->cus * 16;
+    hipLaunchKernelGGL(smear_kernel, dim3((unsigned)(smear_blocks < smear_cap ? smear_blocks : smear_cap)), dim3(256), 0, st,
+                       reinterpret_cast<const uint64_t*>(flag), text_bytes, reinterpret_cast<uint64_t*>(cand),
                        reinterpret_cast<unsigned long long*>(n_cand), W.counters + 7);
     HIP_TRY(hipGetLastError());
     return MDD_OK;
@@ -1951,6 +1923,7 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     REQUIRE(text_bytes < (1ULL << POS_BITS), "mdd_substr_mark_sorted: text_bytes must be below 2^36 (use mdd_substr_mark beyond)");
     REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "mdd_substr_mark_sorted: part=%d outside [0,%d)", part, n_parts);
     REQUIRE(!cand || window >= (int)AN_MINWIN, "mdd_substr_mark_sorted: the candidate filter needs window >= %u", AN_MINWIN);
+    REQUIRE((reinterpret_cast<uintptr_t>(cand) & 7u) == 0, "mdd_substr_mark_sorted: cand must be 8-byte aligned");
     if (n_docs == 0 || text_bytes == 0) return MDD_OK;
     REQUIRE(text && offsets && ent_a && ent_b && d1_ws && ws && dup, "mdd_substr_mark_sorted: NULL buffer");
     REQUIRE((reinterpret_cast<uintptr_t>(text) & 3u) == 0, "mdd_substr_mark_sorted: text must be 4-byte aligned");
@@ -1996,7 +1969,7 @@ extern "C" int mdd_substr_mark_sorted(mdd_ctx* ctx, const uint8_t* text, uint64_
     E.part = (uint32_t)part;
     E.n_parts = (uint32_t)n_parts;
     E.d1 = d1_ws;
-    E.cand = cand;
+    E.cand = reinterpret_cast<const uint64_t*>(cand);
     uint64_t w = waves < n_docs + max_items ? waves : n_docs + max_items;
     // guided self-scheduling: a claim takes (items left) >> batch_shift items, at most max_batch.  Without the filter an item
     // is ~30 rounds of hashing and single items at the end balance the waves; with it an item is a few microseconds and the

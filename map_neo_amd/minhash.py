@@ -488,7 +488,7 @@ class Engine:
                 cap_a = min(cap_a, max(slack + (text_bytes + 71) // 8, table_bytes // per_win))
                 ent_a, ent_b = self.empty(cap_a, torch.int64), self.empty(cap_a, torch.int64)
                 d1 = self.empty(cap_a, torch.int16)
-                cand = self.empty(max(8, text_bytes), torch.uint8)
+                cand = self.empty(((text_bytes >> 6) + 2) * 8, torch.uint8)      # MDD_SUBSTR_CAND_BYTES: a bit per text byte
                 n_cand = torch.zeros(1, dtype=torch.int64, device=self.device)
                 _lib.check(self.L.mdd_substr_candidates(self.ctx, _ptr(text), text_bytes, _ptr(offsets), n, window, _ptr(ent_a), _ptr(ent_b),
                                                         cap_a, _ptr(d1), _ptr(ws), ws.numel(), _ptr(cand), _ptr(n_cand), _ptr(dup)),
