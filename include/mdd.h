@@ -368,8 +368,8 @@ int mdd_substr_mark(mdd_ctx* ctx, const uint8_t* text, uint64_t text_bytes, cons
  *          mark_sorted.  *n_cand == 0 then means dup is final.  The anchors' leaves follow the size of the text (2^20
  *          leaves up to ~2.2 GB, 2^21 / 2^22 beyond) and a leaf above 384 anchors -- every leaf once a call holds more
  *          than ~9 GB -- is settled in rounds over shares of the tag space, so one call takes any text below 2^36 bytes
- *          (27 GB / 12.5 M documents: 0.35 s for the stage, one pass).  On C2 (1 M documents, 15 % near-copies) 2 % of the
- *          windows remain for mark_sorted and the stage takes 29.5 instead of 79 ms (filter alone, window != 50: 28 %
+ *          (27 GB / 12.5 M documents: 0.33 s for the stage, one pass).  On C2 (1 M documents, 15 % near-copies) 2 % of the
+ *          windows remain for mark_sorted and the stage takes 24.5 instead of 79 ms (filter alone, window != 50: 28 %
  *          remain, 61 ms). */
 #define MDD_SUBSTR_SORTED_WS_WORDS 11672587ull
 #define MDD_SUBSTR_CAND_BYTES(text_bytes) ((((uint64_t)(text_bytes) >> 6) + 2) * 8) /* candidate bitmap: a bit per text byte + a spare word */
