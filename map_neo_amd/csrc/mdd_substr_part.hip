@@ -24,8 +24,8 @@
 // inside it) the one with the smallest hash, leftmost on ties -- a function of the window's bytes alone.  Consecutive
 // windows mostly select the same k-gram: one ANCHOR per ~10 windows.  The anchors (10 % of the entries) go through the
 // same two-level sort; a leaf pass flags every anchor whose key occurs twice (key equality only: a false match merely
-// lets windows through); a streaming pass turns anchor flags into window flags (cand[p] = any flagged anchor in
-// [p, p + 18]: a superset of "p's own anchor is flagged").  emit_kernel then skips every window whose flag is clear.
+// lets windows through); a streaming pass turns anchor flags into window flags (bit p of cand = any flagged anchor in
+// [p, p + 18]: a superset of "p's own anchor is flagged"; both are bitmaps).  emit_kernel then skips every window whose bit is clear.
 // Everything the filter does errs on the side of keeping a window, so the marks are those of the unfiltered method.
 #include "mdd_shingle.h"
 
@@ -1824,7 +1824,8 @@ extern "C" int mdd_substr_candidates(mdd_ctx* ctx, const uint8_t* text, uint64_t
                 (reinterpret_cast<uintptr_t>(cand) & 7u) == 0,
             "mdd_substr_candidates: ent_a, ent_b, ws, cand must be 8-byte aligned, d1_ws 2-byte aligned");
     const uint64_t waves = (uint64_t)ctx->cus * 4 * 7;
-    // ent_b doubles as the anchor flags (one byte per text position + 64) once the sort is done with it
+    // ent_b doubles as the anchor flags (a bit per text position, (text_bytes >> 6) + 3 words) once the sort is done with it;
+    // the bound below is the one-byte-per-position layout's and stays: callers size ent_b by it
     REQUIRE(ent_cap >= waves * EMIT_CHUNK + TILE1 && ent_cap < (1ULL << 40) && ent_cap >= (text_bytes + 64 + 7) / 8,
             "mdd_substr_candidates: ent_cap=%llu too small (need max(%llu, (text_bytes + 71) / 8); anchors beyond it only switch the filter off)",
             (unsigned long long)ent_cap, (unsigned long long)(waves * EMIT_CHUNK + TILE1));
