@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extended run of tests/test_gpu_fuzz.py::test_random_exact_stages' sweep: exact substring dedup with BOTH methods (the sorted
 method forced on small inputs, where `auto` would take the table method), paragraph and exact document dedup, against the
-oracle restatement.  python tools/fuzz_exact_more.py [n_seeds]"""
+oracle restatement.  python tools/fuzz_exact_more.py [n_seeds] [first_seed]"""
 import os
 import sys
 
@@ -16,9 +16,10 @@ from oracle import ref_exact as RX
 import test_gpu_fuzz as F
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # a later range of seeds: [first_seed, first_seed + n_seeds)
 eng = Engine(0)
 bad = 0
-for seed in range(n_seeds):
+for seed in range(first_seed, first_seed + n_seeds):
     rng = np.random.Generator(np.random.PCG64(70_000 + seed))
     pieces = [p.replace("\n", " ") for p in F._docs(rng, 40) if p] or ["x"]
     docs = []

@@ -2,7 +2,7 @@
 """Extended run of tests/test_gpu_jsonl.py::test_wave_scanner_equals_thread_scanner_on_mutated_lines: per seed ~8 000 lines
 (valid rows and the same rows with bytes flipped, dropped and inserted), the wave-per-line scan kernel against the
 thread-per-line one (status, content range, decoded text, id token of every line) and against the pure-Python reader
-(json.loads per line) on the lines that decode as utf-8.  python tools/fuzz_jsonl_more.py [n_seeds]"""
+(json.loads per line) on the lines that decode as utf-8.  python tools/fuzz_jsonl_more.py [n_seeds] [first_seed]"""
 import json
 import os
 import sys
@@ -19,13 +19,14 @@ from map_neo_amd.minhash import Engine, padded_size
 from test_hostio import TRICKY
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # a later range of seeds: [first_seed, first_seed + n_seeds)
 eng = Engine(0)
 pools = [(0x20, 0x7F), (0x80, 0x7FF), (0x800, 0xD7FF), (0xE000, 0xFFFF), (0x10000, 0x10FFFF), (0x00, 0x20)]
 inserts = [b"\\", b'"', b"\\u", b"\\ud83d", b"\\ude00", b"\\udc00\\ud800", b"\xc3", b"\xa9", b"\xe4\xb8", b"\xf0\x9f", b"\xff", b"\xed\xa0\x80", b"{", b"}",
            b"[", b"]", b",", b":", b"\t", b"\x01", b"\x1c", b" ", b"0", b"-", b"e", b".", b"tru", b"null", b"\\x", b"\\\\", b'\\"']
 bad = total = 0
 tmp = tempfile.mkdtemp(prefix="mdd_fj_")
-for seed in range(n_seeds):
+for seed in range(first_seed, first_seed + n_seeds):
     rng = np.random.Generator(np.random.PCG64(90_000 + seed))
     base_rows = [t for t in TRICKY if "\n" not in t and "\r" not in t]
     for i in range(600):

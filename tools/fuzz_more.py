@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended run of tests/test_gpu_fuzz.py's random sweep (signatures and labels against the C oracle) over many more seeds than
-the test suite affords, with longer documents so that scan windows, segments and claims interact.  python tools/fuzz_more.py [n_seeds]"""
+the test suite affords, with longer documents so that scan windows, segments and claims interact.  python tools/fuzz_more.py [n_seeds] [first_seed]"""
 import os
 import sys
 
@@ -13,9 +13,10 @@ from oracle import ref_c as RC
 import test_gpu_fuzz as F
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # a later range of seeds: [first_seed, first_seed + n_seeds)
 eng = Engine(0)
 bad = 0
-for seed in range(n_seeds):
+for seed in range(first_seed, first_seed + n_seeds):
     rng = np.random.Generator(np.random.PCG64(50_000 + seed))
     docs = F._docs(rng, 120)
     # some long documents (several scan windows / segments), with leading / trailing / runs of spaces
