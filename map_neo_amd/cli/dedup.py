@@ -71,7 +71,7 @@ def _parse_shard(task):
     name = os.path.basename(path)
     if path.lower().endswith((".parquet", ".pq")):
         r = hostio.read_parquet_shard(path, content_field, id_field, normalize_en=(normalize == "en"))
-        row_of = list(range(len(r["ids"])))
+        row_of = None                                 # row k is row k
     else:
         j = hostio.read_jsonl_shard(path, content_field, id_field, normalize_en=(normalize == "en"), on_error="skip")
         r = {"ids": j["ids"], "cand": j["cand"], "text": j["text"], "offsets": j["offsets"],
@@ -79,9 +79,10 @@ def _parse_shard(task):
              "raw_offsets": np.zeros(1, np.uint64), "raw": np.zeros(0, np.int64)}
         row_of = j["line_no"].tolist()
     r["synthetic"] = False
-    for k, rid in enumerate(r["ids"]):
-        if rid is None:
-            r["ids"][k], r["synthetic"] = f"{name}@{int(row_of[k])}", True
+    if None in r["ids"]:                              # (a scan in C: nearly every shard has all its ids)
+        for k, rid in enumerate(r["ids"]):
+            if rid is None:
+                r["ids"][k], r["synthetic"] = f"{name}@{k if row_of is None else int(row_of[k])}", True
     return r
 
 
@@ -187,7 +188,7 @@ def run(args, engine_factory=None) -> dict:
                                              args.width, args.ngram_unit, args.seed)
                 sig[eng.to_device(r["raw"])] = s_raw
             sigs.append(sig)
-            cand_ids.extend(ids[i] for i in cand.tolist())
+            cand_ids.extend(ids if len(cand) == len(ids) else [ids[i] for i in cand.tolist()])
         t1 = time.time()
         state = None
         if resume:
@@ -232,7 +233,8 @@ def run(args, engine_factory=None) -> dict:
         in_cluster = labels != gidx
         in_cluster[labels[in_cluster]] = True
         mine = np.flatnonzero(in_cluster[doc_base: doc_base + n])
-        pairs = [(int(labels[doc_base + k]), cand_ids[k], doc_base + int(k)) for k in mine.tolist()]
+        mine_l = mine.tolist()
+        pairs = list(zip(labels[doc_base + mine].tolist(), [cand_ids[k] for k in mine_l], (mine + doc_base).tolist()))
         if distributed:
             # in rounds of 200 k entries per rank: all_gather_object pickles into one message per call, and no
             # collective call here should come near 1 GiB (map_neo_amd.dedup.COLLECTIVE_BYTES)
@@ -248,23 +250,34 @@ def run(args, engine_factory=None) -> dict:
             all_pairs = [p for part in all_parts for p in part]
         else:
             all_pairs = pairs
-        # representative: smallest id (EN:145) unless ids were synthesised, then first in input order
+        # representative: smallest id (EN:145) unless ids were synthesised, then first in input order -- all_pairs is in
+        # global document order (ranks in order, each rank's documents in order), so that is the first one met
         rep = {}
-        for l, d, g in all_pairs:
-            if l not in rep or ((g, d) if any_synth else (d, g)) < rep[l][0]:
-                rep[l] = ((g, d) if any_synth else (d, g), d)
-        rep = {l: v[1] for l, v in rep.items()}
+        if any_synth:
+            for l, d, _ in all_pairs:
+                if l not in rep:
+                    rep[l] = d
+        else:
+            get = rep.get
+            for l, d, _ in all_pairs:
+                r = get(l)
+                if r is None or d < r:
+                    rep[l] = d
         remove_ids = {d for l, d, _ in all_pairs if d != rep[l]}
         t2 = time.time()
         suffix = ".part%05d" % rank if distributed else ""
+        # the id lists are 10^5 ... 10^6 entries per rank: one encoder, one join and one write per file (json.dumps with a
+        # keyword builds an encoder per call, an f-string per id is a Python-level loop)
+        enc = json.JSONEncoder(ensure_ascii=False).encode          # == json.dumps(x, ensure_ascii=False)
         with open(os.path.join(args.output_dir, "clusters.jsonl" + suffix), "w", encoding="utf8") as f:
-            for l, d, _ in pairs:
-                f.write(json.dumps({"doc_id": d, "cluster": rep[l]}, ensure_ascii=False) + "\n")
+            f.write("".join(['{"doc_id": %s, "cluster": %s}\n' % (enc(d), enc(rep[l])) for l, d, _ in pairs]))
         with open(os.path.join(args.output_dir, "removed_ids.txt" + suffix), "w", encoding="utf8") as fr, \
                 open(os.path.join(args.output_dir, "kept_ids.txt" + suffix), "w", encoding="utf8") as fk:
-            gone = [d in remove_ids for d in all_ids]
-            fr.write("".join(f"{d}\n" for d, g in zip(all_ids, gone) if g))      # (one write per list, not one per id)
-            fk.write("".join(f"{d}\n" for d, g in zip(all_ids, gone) if not g))
+            removed = [d for d in all_ids if d in remove_ids]
+            kept = [d for d in all_ids if d not in remove_ids] if removed else all_ids
+            for fh, lst in ((fr, removed), (fk, kept)):
+                if lst:
+                    fh.write("\n".join(map(str, lst)) + "\n")
         kept_rows = None
         if args.write_shards:
             os.makedirs(os.path.join(args.output_dir, "shards"), exist_ok=True)

@@ -108,8 +108,16 @@ def main():
                            os.path.join(pin, f"shard-{s_:04d}.parquet"))
         t_pq = time.time() - t0
         t0 = time.time()
-        stats = stage.run(stage.build_parser().parse_args(["--input_dir", pin, "--output_dir", os.path.join(root, "out"),
-                                                           "--normalize", "en", "--workers", str(workers)]))
+        pargs = stage.build_parser().parse_args(["--input_dir", pin, "--output_dir", os.path.join(root, "out"),
+                                                 "--normalize", "en", "--workers", str(workers)])
+        if os.environ.get("MDD_E2E_PROFILE"):     # where the host's time goes: top of the cumulative profile on stderr
+            import cProfile
+            import pstats
+            prof = cProfile.Profile()
+            stats = prof.runcall(stage.run, pargs)
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
+        else:
+            stats = stage.run(pargs)
         wall = time.time() - t0
         stats.update({"mode": mode, "docs": n, "text_bytes": int(o[-1]), "wall_s": wall, "docs_per_s": n / wall, "shards": shards,
                       "workers": workers, "make_parquet_s": t_pq})
